@@ -1,0 +1,208 @@
+"""ctypes binding of libaprilslam.so (include/aprilslam.h).  No fallback: if the HIP library
+is missing or no gfx950 device is usable, every call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaprilslam.so")
+
+
+class AslError(RuntimeError):
+    pass
+
+
+class AslDetection(C.Structure):
+    _fields_ = [("id", C.c_int32), ("hamming", C.c_int32), ("margin", C.c_float), ("frame", C.c_int32),
+                ("center", C.c_double * 2), ("corners", (C.c_double * 2) * 4)]
+
+
+class AslPose(C.Structure):
+    _fields_ = [("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("T", C.c_double * 16), ("ok", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class AslDebugQuad(C.Structure):
+    _fields_ = [("p", (C.c_double * 2) * 4), ("cluster", C.c_uint64), ("frame", C.c_int32), ("reversed_border", C.c_int32)]
+
+
+DET_DTYPE = np.dtype([("id", "<i4"), ("hamming", "<i4"), ("margin", "<f4"), ("frame", "<i4"),
+                      ("center", "<f8", (2,)), ("corners", "<f8", (4, 2))])
+POSE_DTYPE = np.dtype([("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)), ("T", "<f8", (4, 4)), ("ok", "<i4"), ("reserved", "<i4")])
+QUAD_DTYPE = np.dtype([("p", "<f8", (4, 2)), ("cluster", "<u8"), ("frame", "<i4"), ("reversed_border", "<i4")])
+assert DET_DTYPE.itemsize == C.sizeof(AslDetection)
+assert POSE_DTYPE.itemsize == C.sizeof(AslPose)
+assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
+
+EXPORTS = [
+    "asl_detector_create", "asl_detector_destroy", "asl_last_error", "asl_version", "asl_detect_gray_u8",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_device", "asl_solve_pnp_batch", "asl_gn_solve",
+    "asl_debug_fetch", "asl_stage_times", "asl_set_profiling",
+]
+
+_lib = None
+
+
+def load():
+    """Load libaprilslam.so and declare the prototypes.  Raises AslError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AslError("libaprilslam.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                       % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, dp, u8p = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    L.asl_last_error.restype = C.c_char_p
+    L.asl_version.restype = C.c_char_p
+    L.asl_detector_create.argtypes = [C.c_char_p, i32, i32, C.c_float, C.c_float, i32, i32, C.POINTER(vp)]
+    L.asl_detector_destroy.argtypes = [vp]
+    L.asl_detector_destroy.restype = None
+    L.asl_detect_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    L.asl_detect_bgr_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    L.asl_detect_batch_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.asl_detect_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double,
+                                          vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.asl_solve_pnp_batch.argtypes = [vp, C.POINTER(C.c_float), dp, dp, i32, C.c_double, dp, dp, dp, u8p, i32]
+    L.asl_gn_solve.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_double, i32,
+                               dp, dp, i32, dp]
+    L.asl_debug_fetch.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.asl_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32, C.POINTER(i32)]
+    L.asl_set_profiling.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise AslError("libaprilslam error %d: %s" % (rc, load().asl_last_error().decode("utf-8", "replace")))
+
+
+class Detector:
+    """Owns one asl_detector (one GPU workspace).  Not re-entrant."""
+
+    def __init__(self, family="tagStandard41h12", threads=1, maxhamming=1, decimate=2.0, blur=0.0, refine_edges=True,
+                 device=0):
+        L = load()
+        self._L = L
+        self._h = C.c_void_p()
+        check(L.asl_detector_create(family.encode(), int(threads), int(maxhamming), float(decimate), float(blur),
+                                    1 if refine_edges else 0, int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.asl_detector_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host images ------------------------------------------------------------------
+    def detect_host(self, images, max_per_frame=256, channels=None):
+        """images: (H,W) / (H,W,3) uint8 array, or (B,H,W[,3]); pass channels=1 for a gray batch whose W is 3.
+        Returns (dets, n_per_frame)."""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[None]
+        elif a.ndim == 3 and a.shape[2] == 3 and channels != 1:
+            a = a[None]
+        if a.ndim == 3:
+            ch = 1
+            B, H, W = a.shape
+        elif a.ndim == 4 and a.shape[3] == 3:
+            ch = 3
+            B, H, W = a.shape[:3]
+        else:
+            raise ValueError("expected (H,W), (H,W,3), (B,H,W) or (B,H,W,3) uint8")
+        stride = W * ch
+        ptrs = (C.c_void_p * B)(*[a[i].ctypes.data for i in range(B)])
+        cap = B * max_per_frame
+        out = np.zeros(cap, dtype=DET_DTYPE)
+        npf = (C.c_int * B)()
+        n = C.c_int()
+        check(self._L.asl_detect_batch_u8(self._h, ptrs, B, ch, W, H, stride, out.ctypes.data, cap, npf, C.byref(n)))
+        if n.value > cap:
+            return self.detect_host(images, max_per_frame=(n.value + B - 1) // B + 1, channels=channels)
+        return out[:n.value], np.array(list(npf), dtype=np.int64)
+
+    # -- frames resident in HBM ---------------------------------------------------------
+    def detect_device(self, data_ptr, n_frames, channels, width, height, stride=None, frame_pitch=None, stream=0,
+                      K=None, dist=None, tag_size=0.0, max_per_frame=256, want_poses=None):
+        stride = stride or width * channels
+        frame_pitch = frame_pitch or stride * height
+        cap = n_frames * max_per_frame
+        out = np.zeros(cap, dtype=DET_DTYPE)
+        want_poses = (K is not None) if want_poses is None else want_poses
+        poses = np.zeros(cap if want_poses else 0, dtype=POSE_DTYPE)
+        npf = (C.c_int * n_frames)()
+        n = C.c_int()
+        dp = C.POINTER(C.c_double)
+        if K is not None:
+            Kc = np.ascontiguousarray(K, dtype=np.float64)
+            dc = np.ascontiguousarray(np.zeros(0) if dist is None else dist, dtype=np.float64).ravel()
+            nd = len(dc)
+            if nd not in (0, 4, 5):
+                raise ValueError("dist must have 0, 4 or 5 coefficients")
+            Kp = Kc.ctypes.data_as(dp)
+            dpp = dc.ctypes.data_as(dp) if nd else None
+        else:
+            Kp, dpp, nd = None, None, 0
+        check(self._L.asl_detect_batch_device(self._h, C.c_void_p(int(data_ptr)), n_frames, channels, width, height, stride,
+                                              frame_pitch, C.c_void_p(int(stream)), Kp, dpp, nd, float(tag_size),
+                                              out.ctypes.data, poses.ctypes.data if want_poses else None, cap, npf,
+                                              C.byref(n)))
+        if n.value > cap:
+            raise AslError("more than %d detections per frame on average; raise max_per_frame" % max_per_frame)
+        return out[:n.value], (poses[:n.value] if want_poses else None), np.array(list(npf), dtype=np.int64)
+
+    def solve_pnp(self, corners, K, dist, tag_size):
+        c = np.ascontiguousarray(np.asarray(corners, dtype=np.float32).reshape(-1, 4, 2))
+        N = c.shape[0]
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        dc = np.ascontiguousarray(np.zeros(0) if dist is None else dist, dtype=np.float64).ravel()
+        if len(dc) not in (0, 4, 5):
+            raise ValueError("dist must have 0, 4 or 5 coefficients")
+        rvec = np.zeros((N, 3)); tvec = np.zeros((N, 3)); T = np.zeros((N, 4, 4)); ok = np.zeros(N, np.uint8)
+        dp = C.POINTER(C.c_double)
+        check(self._L.asl_solve_pnp_batch(self._h, c.ctypes.data_as(C.POINTER(C.c_float)), Kc.ctypes.data_as(dp),
+                                          dc.ctypes.data_as(dp) if len(dc) else None, len(dc), float(tag_size),
+                                          rvec.ctypes.data_as(dp), tvec.ctypes.data_as(dp), T.ctypes.data_as(dp),
+                                          ok.ctypes.data_as(C.POINTER(C.c_uint8)), N))
+        return rvec, tvec, T, ok.astype(bool)
+
+    # -- introspection for the parity tests ------------------------------------------------
+    def debug_counters(self):
+        buf = np.zeros(16, dtype=np.int64)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, 5, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        return buf
+
+    def debug_image(self, what):
+        c = self.debug_counters()
+        B, sw, sh = int(c[0]), int(c[1]), int(c[2])
+        dt = np.uint8 if what in (0, 1) else np.uint32
+        buf = np.zeros((B, sh, sw), dtype=dt)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, what, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        return buf
+
+    def debug_quads(self, cap=65536):
+        buf = np.zeros(cap, dtype=QUAD_DTYPE)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, 4, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        return buf[:n.value]
+
+    def set_profiling(self, on=True):
+        check(self._L.asl_set_profiling(self._h, 1 if on else 0))
+
+    def stage_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = C.c_int()
+        check(self._L.asl_stage_times(self._h, names, ms, 16, C.byref(n)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}

@@ -1,0 +1,576 @@
+// libaprilslam.so -- host side of the C ABI declared in include/aprilslam.h.
+// gfx950 only.  One asl_detector owns a device workspace sized for its largest batch and
+// submits the whole detector (+ optional PnP) as one chain of launches on one HIP stream.
+#include "../../include/aprilslam.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "asl_common.h"
+#include "tag_standard41h12.inc"
+
+#include "k_threshold.inc"
+#include "k_cc.inc"
+#include "k_cluster.inc"
+#include "k_quad.inc"
+#include "k_decode.inc"
+#include "k_pnp.inc"
+#include "k_gn.inc"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) return fail(ASL_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t want)
+    {
+        if (want <= n) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return -1; }
+        n = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+#define MAX_STAGES 16
+
+struct asl_detector {
+    int device = 0;
+    int maxhamming = 1;
+    int decimate = 2;
+    int refine = 1;
+    FamilyDev fam;
+    unsigned long long *d_codes = nullptr;
+
+    // capacities (grow on overflow)
+    unsigned int hash_slots_per_frame = 8192;
+    unsigned int clusters_per_frame = 1024;
+    unsigned int dets_per_frame = 256;
+    double points_per_pixel = 0.5;
+
+    // workspace
+    DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
+    DevBuf<unsigned int> parent, sizes;
+    DevBuf<unsigned long long> hkeys, points;
+    DevBuf<ClusterStat> hstats;
+    DevBuf<int> slot_cluster;
+    DevBuf<ClusterRec> clusters;
+    DevBuf<QuadRec> quads;
+    DevBuf<double> scratch;
+    DevBuf<DetRec> dets;
+    DevBuf<long long> counters;
+    DevBuf<float> pnp_corners;
+    DevBuf<double> pnp_out;
+    DevBuf<uint8_t> pnp_ok;
+    GnWorkspace gn;
+
+    // sizes used by the last batch
+    Geom last{};
+    unsigned int nslots = 0, max_clusters = 0, max_points = 0, max_dets = 0;
+    long long last_counters[CNT__N] = {0};
+    std::vector<DetRec> host_dets;
+
+    // profiling
+    int profiling = 0;
+    hipEvent_t ev[MAX_STAGES + 1] = {nullptr};
+    int nev = 0;
+    const char *stage_names[MAX_STAGES] = {nullptr};
+    float stage_ms[MAX_STAGES] = {0};
+    int nstages = 0;
+};
+
+static const char *kVersion = "aprilslam 0.1 gfx950 (HIP, tagStandard41h12)";
+
+extern "C" const char *asl_last_error(void) { return g_err.c_str(); }
+extern "C" const char *asl_version(void) { return kVersion; }
+
+extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamming, float decimate, float blur,
+                                   int refine_edges, int device, asl_detector **out)
+{
+    (void)nthreads;  // host threading is meaningless here: the parallelism is the GPU grid
+    if (!out) return fail(ASL_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!family || strcmp(family, "tagStandard41h12") != 0)
+        return fail(ASL_EINVAL, "unknown tag family '%s' (supported: tagStandard41h12)", family ? family : "(null)");
+    if (!(decimate >= 1.0f) || decimate != std::floor(decimate) || decimate > 8.0f)
+        return fail(ASL_EINVAL, "decimate must be an integer value in [1, 8] (got %g)", (double)decimate);
+    if (blur != 0.0f) return fail(ASL_EINVAL, "blur (quad_sigma) != 0 is not supported (the reference never sets it)");
+    if (maxhamming < 0 || maxhamming > 3) return fail(ASL_EINVAL, "maxhamming must be in [0, 3]");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(ASL_EDEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(ASL_EINVAL, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    asl_detector *d = new asl_detector();
+    d->device = device;
+    d->maxhamming = maxhamming;
+    d->decimate = (int)decimate;
+    d->refine = refine_edges ? 1 : 0;
+    memset(&d->fam, 0, sizeof d->fam);
+    d->fam.nbits = kTag41h12NBits;
+    d->fam.width_at_border = kTag41h12WidthAtBorder;
+    d->fam.total_width = kTag41h12TotalWidth;
+    d->fam.reversed_border = 1;
+    d->fam.ncodes = kTag41h12NCodes;
+    for (int i = 0; i < kTag41h12NBits; i++) { d->fam.bit_x[i] = kTag41h12BitX[i]; d->fam.bit_y[i] = kTag41h12BitY[i]; }
+    if (hipMalloc((void **)&d->d_codes, sizeof(unsigned long long) * kTag41h12NCodes) != hipSuccess) {
+        delete d;
+        return fail(ASL_ENOMEM, "hipMalloc(code book) failed");
+    }
+    if (hipMemcpy(d->d_codes, kTag41h12Codes, sizeof(unsigned long long) * kTag41h12NCodes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d->d_codes);
+        delete d;
+        return fail(ASL_EDEVICE, "hipMemcpy(code book) failed");
+    }
+    d->fam.codes = d->d_codes;
+    *out = d;
+    return ASL_OK;
+}
+
+extern "C" void asl_detector_destroy(asl_detector *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
+    d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hstats.release();
+    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->dets.release();
+    d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
+    d->gn.release();
+    if (d->d_codes) (void)hipFree(d->d_codes);
+    for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
+    delete d;
+}
+
+extern "C" int asl_set_profiling(asl_detector *d, int enabled)
+{
+    if (!d) return fail(ASL_EINVAL, "detector is NULL");
+    d->profiling = enabled ? 1 : 0;
+    if (enabled)
+        for (int i = 0; i <= MAX_STAGES; i++)
+            if (!d->ev[i]) HIPCHK(hipEventCreate(&d->ev[i]));
+    return ASL_OK;
+}
+
+extern "C" int asl_stage_times(asl_detector *d, const char **names, float *ms, int max_n, int *n)
+{
+    if (!d || !n) return fail(ASL_EINVAL, "NULL argument");
+    int k = std::min(max_n, d->nstages);
+    for (int i = 0; i < k; i++) { if (names) names[i] = d->stage_names[i]; if (ms) ms[i] = d->stage_ms[i]; }
+    *n = k;
+    return ASL_OK;
+}
+
+static unsigned int next_pow2(unsigned long long v)
+{
+    unsigned long long p = 1;
+    while (p < v) p <<= 1;
+    return (unsigned int)p;
+}
+
+static int make_geom(asl_detector *d, int n_frames, int channels, int w, int h, int stride, size_t frame_pitch, Geom *g)
+{
+    if (n_frames <= 0 || n_frames > 65535) return fail(ASL_EINVAL, "n_frames must be in [1, 65535] (got %d)", n_frames);
+    if (channels != 1 && channels != 3) return fail(ASL_EINVAL, "channels must be 1 (gray) or 3 (BGR), got %d", channels);
+    if (w < 8 || h < 8 || w > 16384 || h > 16384) return fail(ASL_EINVAL, "unsupported image size %dx%d", w, h);
+    if (stride < w * channels) return fail(ASL_EINVAL, "stride %d smaller than a row (%d bytes)", stride, w * channels);
+    g->w = w; g->h = h; g->stride = stride; g->channels = channels; g->f = d->decimate;
+    g->sw = 1 + (w - 1) / g->f; g->sh = 1 + (h - 1) / g->f;
+    g->tw = g->sw / TILESZ; g->th = g->sh / TILESZ;
+    g->nframes = n_frames; g->frame_pitch = frame_pitch;
+    g->npix = (size_t)g->sw * g->sh;
+    if (g->npix >= (1u << 24)) return fail(ASL_EINVAL, "decimated frame has %zu pixels; the cluster key holds 2^24", g->npix);
+    return ASL_OK;
+}
+
+static int ensure_workspace(asl_detector *d, const Geom &g)
+{
+    size_t B = (size_t)g.nframes;
+    size_t total = B * g.npix;
+    d->nslots = next_pow2(std::max<unsigned long long>(16384ull, (unsigned long long)B * d->hash_slots_per_frame));
+    unsigned long long mc = (unsigned long long)B * d->clusters_per_frame;
+    d->max_clusters = (unsigned int)std::min<unsigned long long>(mc, 0x7FFFFFFFull);
+    unsigned long long mp = (unsigned long long)((double)total * d->points_per_pixel) + 65536ull;
+    d->max_points = (unsigned int)std::min<unsigned long long>(mp, 0xFFFFFFF0ull);
+    d->max_dets = (unsigned int)std::min<unsigned long long>((unsigned long long)B * d->dets_per_frame, 0x7FFFFFFFull);
+    int bad = 0;
+    bad |= d->dgray.ensure(total);
+    bad |= d->thresh.ensure(total);
+    bad |= d->tmin.ensure(B * (size_t)std::max(1, g.tw * g.th));
+    bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th));
+    bad |= d->parent.ensure(total);
+    bad |= d->sizes.ensure(total);
+    bad |= d->hkeys.ensure(d->nslots);
+    bad |= d->hstats.ensure(d->nslots);
+    bad |= d->slot_cluster.ensure(d->nslots);
+    bad |= d->clusters.ensure(d->max_clusters);
+    bad |= d->quads.ensure(d->max_clusters);
+    bad |= d->points.ensure(d->max_points);
+    bad |= d->scratch.ensure((size_t)d->max_points * 8);
+    bad |= d->dets.ensure(d->max_dets);
+    bad |= d->counters.ensure(CNT__N);
+    if (bad) return fail(ASL_ENOMEM, "device workspace allocation failed (%zu frames of %dx%d)", B, g.sw, g.sh);
+    return ASL_OK;
+}
+
+#define STAGE(name)                                                        \
+    do {                                                                   \
+        if (d->profiling && d->nev < MAX_STAGES) {                         \
+            d->stage_names[d->nev] = name;                                 \
+            HIPCHK(hipEventRecord(d->ev[d->nev], st));                     \
+            d->nev++;                                                      \
+        }                                                                  \
+    } while (0)
+
+// enqueue the whole detector for frames resident at d_frames; no host sync
+static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
+{
+    dim3 blk(64, 4, 1);
+    int twx = (g.sw + TILESZ - 1) / TILESZ, thx = (g.sh + TILESZ - 1) / TILESZ;
+    unsigned int B = (unsigned int)g.nframes;
+    d->nev = 0;
+    HIPCHK(hipMemsetAsync(d->counters.p, 0, sizeof(long long) * CNT__N, st));
+    HIPCHK(hipMemsetAsync(d->sizes.p, 0, sizeof(unsigned int) * B * g.npix, st));
+
+    STAGE("threshold");
+    hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
+    hipLaunchKernelGGL(k_threshold, dim3((twx + 63) / 64, (g.sh + 3) / 4, B), blk, 0, st, d->dgray.p, g, d->tmin.p, d->tmax.p, d->thresh.p);
+
+    STAGE("components");
+    dim3 pgrid((g.sw + 63) / 64, (g.sh + 3) / 4, B);
+    hipLaunchKernelGGL(k_cc_init, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
+    hipLaunchKernelGGL(k_cc_merge, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
+    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
+
+    STAGE("clusters");
+    hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots);
+    hipLaunchKernelGGL(k_cluster_count, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hstats.p,
+                       d->nslots - 1, d->counters.p);
+    int tag_width = d->fam.width_at_border / g.f;
+    if (tag_width < 3) tag_width = 3;
+    hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots, g,
+                       tag_width, d->fam.reversed_border ? 1 : 0, d->fam.reversed_border ? 0 : 1, d->clusters.p,
+                       d->slot_cluster.p, d->max_clusters, d->max_points, d->counters.p);
+    hipLaunchKernelGGL(k_cluster_scatter, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->nslots - 1,
+                       d->slot_cluster.p, d->clusters.p, d->points.p);
+
+    STAGE("quads");
+    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 4096u);
+    hipLaunchKernelGGL(k_fit_quads, dim3(qgrid), dim3(QF_THREADS), QF_LDS_BYTES, st, d->clusters.p, d->counters.p, d->max_clusters,
+                       d->points.p, d->dgray.p, g, tag_width, d->scratch.p, d->quads.p);
+
+    STAGE("decode");
+    unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
+    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
+                       d->maxhamming, d->refine, d->dets.p, d->max_dets, d->counters.p);
+
+    if (cam) {
+        STAGE("pnp");
+        hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + 63) / 64), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam);
+    }
+    if (d->profiling && d->nev <= MAX_STAGES) HIPCHK(hipEventRecord(d->ev[d->nev], st));
+    HIPCHK(hipGetLastError());
+    return ASL_OK;
+}
+
+static CamDev make_cam(const double *K, const double *dist, int n_dist, double tag_size)
+{
+    CamDev c;
+    c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+    c.k1 = c.k2 = c.p1 = c.p2 = c.k3 = 0;
+    if (dist && n_dist >= 4) { c.k1 = dist[0]; c.k2 = dist[1]; c.p1 = dist[2]; c.p2 = dist[3]; }
+    if (dist && n_dist >= 5) c.k3 = dist[4];
+    c.half = (double)(float)(tag_size / 2);  // object corners are float32 in the reference
+    return c;
+}
+
+// ---- host-side S8: drop overlapping duplicates, sort by id (tag_detector.py:27 re-sorts by id anyway)
+static bool seg_intersect(const double *a, const double *b, const double *c, const double *dd)
+{
+    double d1 = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+    double d2 = (b[0] - a[0]) * (dd[1] - a[1]) - (b[1] - a[1]) * (dd[0] - a[0]);
+    double d3 = (dd[0] - c[0]) * (a[1] - c[1]) - (dd[1] - c[1]) * (a[0] - c[0]);
+    double d4 = (dd[0] - c[0]) * (b[1] - c[1]) - (dd[1] - c[1]) * (b[0] - c[0]);
+    return ((d1 > 0) != (d2 > 0)) && ((d3 > 0) != (d4 > 0));
+}
+static bool point_in_quad(const double q[4][2], const double *p)
+{
+    int pos = 0, neg = 0;
+    for (int i = 0; i < 4; i++) {
+        const double *a = q[i], *b = q[(i + 1) & 3];
+        double c = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]);
+        if (c > 0) pos++; else if (c < 0) neg++;
+    }
+    return pos == 0 || neg == 0;
+}
+static bool quads_overlap(const double a[4][2], const double b[4][2])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            if (seg_intersect(a[i], a[(i + 1) & 3], b[j], b[(j + 1) & 3])) return true;
+    return point_in_quad(a, b[0]) || point_in_quad(b, a[0]);
+}
+static int prefer_smaller(int pref, double q0, double q1)
+{
+    if (pref) return pref;
+    if (q0 < q1) return -1;
+    if (q1 < q0) return 1;
+    return 0;
+}
+static bool det_less(const DetRec &a, const DetRec &b)
+{
+    if (a.frame != b.frame) return a.frame < b.frame;
+    if (a.id != b.id) return a.id < b.id;
+    if (a.hamming != b.hamming) return a.hamming < b.hamming;
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 2; k++)
+            if (a.corners[i][k] != b.corners[i][k]) return a.corners[i][k] < b.corners[i][k];
+    return false;
+}
+static bool det_key_less(const DetRec &a, const DetRec &b)
+{
+    if (a.frame != b.frame) return a.frame < b.frame;
+    return a.key < b.key;
+}
+
+// dedup within [lo, hi) (one frame, already in cluster-key order = the oracle's visiting order)
+static void dedup_frame(std::vector<DetRec> &v, size_t lo, size_t hi, std::vector<DetRec> &out)
+{
+    std::vector<DetRec> d(v.begin() + lo, v.begin() + hi);
+    int n = (int)d.size();
+    for (int i0 = 0; i0 < n; i0++) {
+        for (int i1 = i0 + 1; i1 < n; i1++) {
+            if (d[i0].id != d[i1].id) continue;
+            if (!quads_overlap(d[i0].corners, d[i1].corners)) continue;
+            int pref = 0;
+            pref = prefer_smaller(pref, d[i0].hamming, d[i1].hamming);
+            pref = prefer_smaller(pref, -d[i0].margin, -d[i1].margin);
+            for (int i = 0; i < 4; i++) {
+                pref = prefer_smaller(pref, d[i0].corners[i][0], d[i1].corners[i][0]);
+                pref = prefer_smaller(pref, d[i0].corners[i][1], d[i1].corners[i][1]);
+            }
+            if (pref < 0) { d.erase(d.begin() + i1); n--; i1--; }
+            else { d.erase(d.begin() + i0); n--; i0--; break; }
+        }
+    }
+    std::sort(d.begin(), d.end(), det_less);
+    out.insert(out.end(), d.begin(), d.end());
+}
+
+static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam,
+                     asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+{
+    for (int attempt = 0; attempt < 4; attempt++) {
+        int rc = ensure_workspace(d, g);
+        if (rc) return rc;
+        rc = enqueue_detect(d, d_frames, g, st, cam);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d->last_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        d->last = g;
+        long long *c = d->last_counters;
+        bool again = false;
+        if (c[CNT_OVERFLOW_HASH]) { d->hash_slots_per_frame *= 4; again = true; }
+        if (c[CNT_OVERFLOW_CLUSTERS] || c[CNT_NCLUSTERS] > (long long)d->max_clusters) { d->clusters_per_frame *= 4; again = true; }
+        if (c[CNT_OVERFLOW_POINTS]) { d->points_per_pixel *= 2; again = true; }
+        if (c[CNT_OVERFLOW_DETS]) { d->dets_per_frame *= 4; again = true; }
+        if (again) {
+            if (attempt == 3) return fail(ASL_ECAPACITY, "work buffers still overflow after growing (hash %lld clusters %lld points %lld dets %lld)",
+                                          c[CNT_OVERFLOW_HASH], c[CNT_OVERFLOW_CLUSTERS], c[CNT_OVERFLOW_POINTS], c[CNT_OVERFLOW_DETS]);
+            continue;
+        }
+        break;
+    }
+    if (d->profiling) {
+        d->nstages = d->nev;
+        for (int i = 0; i < d->nev; i++) HIPCHK(hipEventElapsedTime(&d->stage_ms[i], d->ev[i], d->ev[i + 1]));
+    }
+    size_t nd = (size_t)d->last_counters[CNT_NDETS];
+    d->host_dets.resize(nd);
+    if (nd) HIPCHK(hipMemcpy(d->host_dets.data(), d->dets.p, nd * sizeof(DetRec), hipMemcpyDeviceToHost));
+    std::sort(d->host_dets.begin(), d->host_dets.end(), det_key_less);
+    std::vector<DetRec> fin;
+    fin.reserve(nd);
+    std::vector<int> counts((size_t)g.nframes, 0);
+    size_t i = 0;
+    while (i < nd) {
+        size_t j = i;
+        while (j < nd && d->host_dets[j].frame == d->host_dets[i].frame) j++;
+        size_t before = fin.size();
+        dedup_frame(d->host_dets, i, j, fin);
+        counts[(size_t)d->host_dets[i].frame] = (int)(fin.size() - before);
+        i = j;
+    }
+    int total = (int)fin.size();
+    int nw = std::min(total, max_out);
+    for (int k = 0; k < nw; k++) {
+        const DetRec &r = fin[(size_t)k];
+        if (out) {
+            asl_detection &o = out[k];
+            o.id = r.id; o.hamming = r.hamming; o.margin = r.margin; o.frame = r.frame;
+            o.center[0] = r.center[0]; o.center[1] = r.center[1];
+            for (int a = 0; a < 4; a++) { o.corners[a][0] = r.corners[a][0]; o.corners[a][1] = r.corners[a][1]; }
+        }
+        if (poses && cam) {
+            asl_pose &p = poses[k];
+            for (int a = 0; a < 3; a++) { p.rvec[a] = r.rvec[a]; p.tvec[a] = r.tvec[a]; }
+            for (int a = 0; a < 16; a++) p.T[a] = r.T[a];
+            p.ok = r.pose_ok; p.reserved = 0;
+        }
+    }
+    if (n_per_frame) for (int f = 0; f < g.nframes; f++) n_per_frame[f] = counts[(size_t)f];
+    if (n_out) *n_out = total;
+    return ASL_OK;
+}
+
+extern "C" int asl_detect_batch_device(asl_detector *d, const void *d_frames, int n_frames, int channels, int w, int h, int stride,
+                                       size_t frame_pitch, void *stream, const double *K, const double *dist, int n_dist,
+                                       double tag_size, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+{
+    if (!d || !d_frames) return fail(ASL_EINVAL, "NULL detector or frames");
+    if (max_out < 0 || (max_out > 0 && !out)) return fail(ASL_EINVAL, "out is NULL");
+    if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
+    HIPCHK(hipSetDevice(d->device));
+    Geom g;
+    int rc = make_geom(d, n_frames, channels, w, h, stride, frame_pitch, &g);
+    if (rc) return rc;
+    if (frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "frame_pitch smaller than one frame");
+    CamDev cam;
+    if (K) cam = make_cam(K, dist, n_dist, tag_size);
+    return run_batch(d, (const uint8_t *)d_frames, g, (hipStream_t)stream, K ? &cam : nullptr, out, poses, max_out, n_per_frame, n_out);
+}
+
+extern "C" int asl_detect_batch_u8(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
+                                   asl_detection *out, int max_out, int *n_per_frame, int *n_out)
+{
+    if (!d || !frames) return fail(ASL_EINVAL, "NULL detector or frames");
+    HIPCHK(hipSetDevice(d->device));
+    Geom g;
+    size_t pitch = (size_t)stride * (size_t)h;
+    int rc = make_geom(d, n_frames, channels, w, h, stride, pitch, &g);
+    if (rc) return rc;
+    if (d->in.ensure(pitch * (size_t)n_frames)) return fail(ASL_ENOMEM, "input staging allocation failed");
+    for (int i = 0; i < n_frames; i++) {
+        if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
+        HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
+    }
+    return run_batch(d, d->in.p, g, nullptr, nullptr, out, nullptr, max_out, n_per_frame, n_out);
+}
+
+extern "C" int asl_detect_gray_u8(asl_detector *d, const uint8_t *gray, int w, int h, int stride, asl_detection *out, int max_out, int *n_out)
+{
+    const uint8_t *fr[1] = {gray};
+    return asl_detect_batch_u8(d, fr, 1, 1, w, h, stride, out, max_out, nullptr, n_out);
+}
+
+extern "C" int asl_detect_bgr_u8(asl_detector *d, const uint8_t *bgr, int w, int h, int stride, asl_detection *out, int max_out, int *n_out)
+{
+    const uint8_t *fr[1] = {bgr};
+    return asl_detect_batch_u8(d, fr, 1, 3, w, h, stride, out, max_out, nullptr, n_out);
+}
+
+extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const double *K, const double *dist, int n_dist,
+                                   double tag_size, double *rvec, double *tvec, double *T, uint8_t *ok, int N)
+{
+    if (!d || !corners || !K || !rvec || !tvec || !T || !ok) return fail(ASL_EINVAL, "NULL argument");
+    if (N < 0) return fail(ASL_EINVAL, "N < 0");
+    if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
+    if (N == 0) return ASL_OK;
+    HIPCHK(hipSetDevice(d->device));
+    if (d->pnp_corners.ensure((size_t)N * 8) || d->pnp_out.ensure((size_t)N * 22) || d->pnp_ok.ensure((size_t)N))
+        return fail(ASL_ENOMEM, "PnP workspace allocation failed");
+    CamDev cam = make_cam(K, dist, n_dist, tag_size);
+    HIPCHK(hipMemcpy(d->pnp_corners.p, corners, sizeof(float) * 8 * (size_t)N, hipMemcpyHostToDevice));
+    double *dr = d->pnp_out.p, *dt = dr + 3 * (size_t)N, *dT = dt + 3 * (size_t)N;
+    hipLaunchKernelGGL(k_pnp_batch, dim3((N + 63) / 64), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(rvec, dr, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tvec, dt, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(T, dT, sizeof(double) * 16 * (size_t)N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ok, d->pnp_ok.p, (size_t)N, hipMemcpyDeviceToHost));
+    return ASL_OK;
+}
+
+extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t bytes, size_t *n_items)
+{
+    if (!d || !dst || !n_items) return fail(ASL_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(d->device));
+    const Geom &g = d->last;
+    size_t total = (size_t)g.nframes * g.npix;
+    if (what >= 0 && what <= 3 && total == 0) return fail(ASL_EINVAL, "no batch has run yet");
+    switch (what) {
+    case 0:
+    case 1: {
+        if (bytes < total) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total);
+        HIPCHK(hipMemcpy(dst, what == 0 ? d->dgray.p : d->thresh.p, total, hipMemcpyDeviceToHost));
+        *n_items = total;
+        return ASL_OK;
+    }
+    case 2:
+    case 3: {
+        if (bytes < total * 4) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total * 4);
+        HIPCHK(hipMemcpy(dst, what == 2 ? d->parent.p : d->sizes.p, total * 4, hipMemcpyDeviceToHost));
+        *n_items = total;
+        return ASL_OK;
+    }
+    case 4: {
+        size_t ncl = (size_t)std::min<long long>(d->last_counters[CNT_NCLUSTERS], (long long)d->max_clusters);
+        std::vector<QuadRec> q(ncl);
+        if (ncl) HIPCHK(hipMemcpy(q.data(), d->quads.p, ncl * sizeof(QuadRec), hipMemcpyDeviceToHost));
+        std::sort(q.begin(), q.end(), [](const QuadRec &a, const QuadRec &b) { return a.key < b.key; });
+        asl_debug_quad *o = (asl_debug_quad *)dst;
+        size_t cap = bytes / sizeof(asl_debug_quad), k = 0;
+        for (size_t i = 0; i < ncl; i++) {
+            if (!q[i].valid) continue;
+            if (k >= cap) return fail(ASL_EINVAL, "dst too small for the quads");
+            for (int a = 0; a < 4; a++) { o[k].p[a][0] = q[i].p[a][0]; o[k].p[a][1] = q[i].p[a][1]; }
+            unsigned long long key = q[i].key;
+            o[k].frame = (int)(key >> 48);
+            o[k].cluster = (((key >> 24) & 0xFFFFFFull) << 32) + (key & 0xFFFFFFull);
+            o[k].reversed_border = q[i].reversed_border;
+            k++;
+        }
+        *n_items = k;
+        return ASL_OK;
+    }
+    case 5: {
+        if (bytes < sizeof(long long) * 16) return fail(ASL_EINVAL, "dst too small");
+        long long *o = (long long *)dst;
+        o[0] = g.nframes; o[1] = g.sw; o[2] = g.sh;
+        o[3] = d->last_counters[CNT_NCLUSTERS]; o[4] = d->last_counters[CNT_NPOINTS]; o[5] = 0;
+        o[6] = d->last_counters[CNT_NDETS]; o[7] = d->nslots; o[8] = d->max_clusters; o[9] = d->max_points; o[10] = d->max_dets;
+        o[11] = d->last_counters[CNT_OVERFLOW_HASH]; o[12] = d->last_counters[CNT_OVERFLOW_CLUSTERS];
+        o[13] = d->last_counters[CNT_OVERFLOW_POINTS]; o[14] = d->last_counters[CNT_OVERFLOW_DETS]; o[15] = 0;
+        *n_items = 16;
+        return ASL_OK;
+    }
+    default:
+        return fail(ASL_EINVAL, "unknown debug item %d", what);
+    }
+}
+
+#include "gn_host.inc"

@@ -1,0 +1,98 @@
+// Shared definitions for the gfx950 kernels of libaprilslam.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ASL_WAVE 64
+#define TILESZ 4
+#define MIN_WHITE_BLACK_DIFF 5
+#define MIN_COMPONENT 25u
+#define MAX_NMAXIMA 10
+#define MAX_LINE_FIT_MSE 10.0
+#define COS_CRITICAL_RAD 0.984807753012208 /* cos(10 deg) */
+#define HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define HASH_MAX_PROBE 512
+
+// Geometry of one batch, passed by value to every kernel.
+struct Geom {
+    int w, h;          // full-resolution frame
+    int stride;        // bytes between rows of a frame
+    int channels;      // 1 = gray, 3 = BGR
+    int f;             // integer decimation factor
+    int sw, sh;        // decimated size
+    int tw, th;        // full 4x4 tiles of the decimated image
+    int nframes;
+    size_t frame_pitch;  // bytes between frames of the input
+    size_t npix;         // sw*sh
+};
+
+// Per-cluster statistics gathered while counting boundary points (hash table payload).
+struct ClusterStat {
+    unsigned int count;
+    unsigned int xmin, ymin, xmax, ymax;  // half-pixel fixed point
+    int sgx, sgy;                         // sum of gx, gy
+    long long sxg;                        // sum of x*gx + y*gy
+};
+
+// A cluster that survived the pre-filter and will be fitted.
+struct ClusterRec {
+    uint64_t key;        // (frame << 48) | (hi << 24) | lo
+    unsigned int offset; // first point in the point pool
+    unsigned int count;
+    unsigned int fill;   // scatter cursor
+    int reversed;        // border polarity: 1 = white inside black
+    float cx, cy;        // bounding-box centre + fixed jitter
+};
+
+struct QuadRec {
+    double p[4][2];  // decimated-image coordinates
+    uint64_t key;
+    int valid;
+    int reversed_border;
+};
+
+struct DetRec {
+    int32_t id, hamming;
+    float margin;
+    int32_t frame;
+    double center[2];
+    double corners[4][2];
+    uint64_t key;  // cluster key, for a deterministic order
+    double rvec[3], tvec[3], T[16];
+    int32_t pose_ok, pad;
+};
+
+struct FamilyDev {
+    int nbits, width_at_border, total_width, reversed_border, ncodes;
+    int bit_x[64], bit_y[64];
+    const unsigned long long *codes;  // device pointer
+};
+
+struct CamDev {
+    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+    double half;  // tag_size/2 rounded through float32 as the reference does
+};
+
+// counters living in device memory (zeroed per batch)
+enum {
+    CNT_NCLUSTERS = 0,  // surviving clusters
+    CNT_NPOINTS,        // points reserved for surviving clusters
+    CNT_NSCRATCH,       // points reserved in the large-cluster scratch pool
+    CNT_NDETS,          // detections appended
+    CNT_OVERFLOW_HASH,
+    CNT_OVERFLOW_POINTS,
+    CNT_OVERFLOW_CLUSTERS,
+    CNT_OVERFLOW_SCRATCH,
+    CNT_OVERFLOW_DETS,
+    CNT_NQUADS,
+    CNT_TOTAL_EMITTED,
+    CNT__N = 16
+};
+
+__device__ __forceinline__ int gray_at(const uint8_t *frame, const Geom &g, int x, int y)
+{
+    const uint8_t *p = frame + (size_t)y * g.stride;
+    if (g.channels == 1) return p[x];
+    int b = p[3 * x], gg = p[3 * x + 1], r = p[3 * x + 2];
+    return (b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15;  // cv2 BGR2GRAY fixed point
+}

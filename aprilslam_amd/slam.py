@@ -1,0 +1,98 @@
+"""`SLAM` facade: host-side mirror of reference src/core/slam.py:9-97.
+
+Per-frame contract used by the reference harness (simulation_engine.py:219-238):
+    detections = slam.detect(frame); for d in detections: slam.get_pose(d); pose = slam.my_pose()
+`process_observations` is the batched entry the multi-GPU path uses after the all-gather.
+The matplotlib visualiser of the reference (slam_visualizer.py) is out of scope; the three
+plotting methods are kept callable and do nothing unless a visualiser object is supplied.
+"""
+import numpy as np
+
+from .slam_graph import SLAMGraph
+from .tag_detector import TagDetector
+
+
+class _NullVisualizer:
+    def slam_graph(self, *a, **k):
+        pass
+
+    def vis_slam(self, *a, **k):
+        pass
+
+    def error_graph(self, *a, **k):
+        pass
+
+
+class SLAM:
+    def __init__(self, logger, camera_params, tag_type="tagStandard41h12", tag_size=0.06, detector=None,
+                 visualizer=None, device=0):
+        self.logger = logger
+        self.logger.info("Initializing SLAM")
+        self.detector = detector if detector is not None else TagDetector(camera_params, tag_type, tag_size, device=device)
+        self.graph = SLAMGraph(logger)
+        self.visualizer = visualizer if visualizer is not None else _NullVisualizer()
+        self.visible_tags = []
+
+    def detect(self, image):
+        detections = self.detector.detect(image)
+        self.visible_tags = [d['id'] for d in detections]
+        return detections
+
+    def get_pose(self, detection):
+        retval, rvec, tvec, T = self.detector.get_pose(detection)
+        if retval:
+            self.graph.add_or_update_node(detection['id'], T, self.visible_tags)
+        return retval, rvec, tvec
+
+    def process_observations(self, ids, transforms, oks=None):
+        """One frame's observations (ids ascending, T camera<-tag each) -> graph update + my_pose()."""
+        self.visible_tags = [int(i) for i in ids]
+        for k, tag_id in enumerate(self.visible_tags):
+            if oks is None or oks[k]:
+                self.graph.add_or_update_node(tag_id, np.asarray(transforms[k], dtype=np.float64), self.visible_tags)
+        return self.my_pose()
+
+    def my_pose(self):
+        """Weighted element-wise mean of world @ local over the visible nodes (slam.py:36-63)."""
+        if not self.visible_tags:
+            return None
+        nodes = self.graph.get_nodes()
+        for node in nodes.values():
+            node.visible = False
+        T_sum = np.zeros((4, 4))
+        count = 0
+        for tag_id in self.visible_tags:
+            node = nodes.get(tag_id)
+            if node is None:
+                continue
+            node.visible = True
+            T = np.matmul(node.world, node.local)
+            T_sum += T / node.weight
+            count += 1 / node.weight
+        if count == 0:
+            return None
+        T_avg = T_sum / count
+        self.graph.estimated_pose = T_avg
+        return T_avg
+
+    def average_distance_to_nodes(self):
+        nodes = self.graph.get_nodes()
+        if not nodes:
+            return 0
+        total = 0
+        for node in nodes.values():
+            total += np.linalg.norm(node.local[:3, 3])
+        return total / len(nodes)
+
+    @property
+    def coordinate_id(self):
+        return self.graph.get_coordinate_id()
+
+    def slam_graph(self):
+        self.visualizer.slam_graph(self.graph.get_nodes())
+
+    def vis_slam(self, ground_truth=None):
+        self.visualizer.vis_slam(self.graph.get_nodes(), self.graph.get_estimated_pose(), ground_truth)
+
+    def error_graph(self, ground_truth_graph):
+        self.visualizer.error_graph(self.graph.get_nodes(), ground_truth_graph)

@@ -1,0 +1,143 @@
+/*
+ * include/aprilslam.h -- C ABI of libaprilslam.so, the MI355X (gfx950) AprilTag-SLAM hot path.
+ *
+ * Drop-in boundary.  The reference reaches its hot path through two native packages:
+ *   apriltag(tag_type).detect(gray)                 reference src/detection/tag_detector.py:11,18,26
+ *   cv2.cvtColor(image, cv2.COLOR_BGR2GRAY)         reference src/detection/tag_detector.py:25
+ *   cv2.solvePnP(obj_points, corners, K, dist)      reference src/detection/tag_detector.py:41
+ *   cv2.Rodrigues(rvec)                             reference src/detection/tag_detector.py:47
+ * Upstream's `apriltag` module is a CPython extension, so there is no existing FFI
+ * signature to copy; the entry points below are what a ctypes binding for that module
+ *  needs.  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ASL_E* code on failure;
+ *     asl_last_error() returns a thread-local message for the last failure.
+ *   - "host" pointers are ordinary process memory, "device" pointers are HIP device
+ *     memory on the detector's GPU (e.g. torch.Tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - images are row-major uint8, `stride` = bytes between rows, 1 channel (gray) or
+ *     3 channels (BGR, as cv2 hands them to TagDetector.detect).
+ *   - pixel convention: pixel (ix, iy) covers [ix, ix+1) x [iy, iy+1), centre at +0.5.
+ *   - one detector per (host thread, stream); a detector is not re-entrant
+ *     (same rule as upstream's detector object).
+ *   - there is NO CPU fallback: without a usable gfx950 device every call fails.
+ */
+#ifndef APRILSLAM_H
+#define APRILSLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASL_OK 0
+#define ASL_EINVAL (-1)      /* bad argument (unknown family, unsupported decimate/blur, NULL pointer ...) */
+#define ASL_EDEVICE (-2)     /* HIP runtime / no GPU */
+#define ASL_ECAPACITY (-3)   /* an internal work buffer overflowed even after growing */
+#define ASL_ENOMEM (-4)
+
+typedef struct asl_detector asl_detector;
+
+/* One detection: the fields of the dict upstream's wrapper returns
+   ('id', 'hamming', 'margin', 'center', 'lb-rb-rt-lt'), plus the frame index inside a batch. */
+typedef struct {
+    int32_t id;
+    int32_t hamming;
+    float margin;
+    int32_t frame;
+    double center[2];
+    double corners[4][2]; /* lb, rb, rt, lt in pixels (reference tag_detector.py:32) */
+} asl_detection;
+
+/* Pose of one detection: what TagDetector.get_pose returns (reference tag_detector.py:30-43). */
+typedef struct {
+    double rvec[3];
+    double tvec[3];
+    double T[16]; /* row-major camera<-tag 4x4 (reference tag_detector.py:45-52) */
+    int32_t ok;   /* solvePnP's retval */
+    int32_t reserved;
+} asl_pose;
+
+/* Replaces `apriltag(family, threads=1, maxhamming=1, decimate=2.0, blur=0.0, refine_edges=True)`
+   (reference tag_detector.py:18 passes the family only; the wrapper's defaults apply).
+   decimate must be an integer value >= 1; blur must be 0 (the reference never sets either).
+   device = HIP device ordinal. */
+int asl_detector_create(const char *family, int nthreads, int maxhamming, float decimate, float blur,
+                        int refine_edges, int device, asl_detector **out);
+void asl_detector_destroy(asl_detector *det);
+const char *asl_last_error(void);
+/* "aprilslam <version> gfx950 ..." */
+const char *asl_version(void);
+
+/* Replaces detector.detect(gray) (reference tag_detector.py:26).  Host image in, detections
+   (sorted by id) out.  *n_out = number found; at most max_out are written. */
+int asl_detect_gray_u8(asl_detector *det, const uint8_t *gray, int w, int h, int stride,
+                       asl_detection *out, int max_out, int *n_out);
+/* Replaces cv2.cvtColor(BGR2GRAY) + detector.detect (reference tag_detector.py:25-27): the
+   gray conversion is fused into the first kernel. */
+int asl_detect_bgr_u8(asl_detector *det, const uint8_t *bgr, int w, int h, int stride,
+                      asl_detection *out, int max_out, int *n_out);
+
+/* Batched form of the two calls above: n_frames host images of identical geometry.
+   channels = 1 (gray) or 3 (BGR).  out holds up to max_out detections in total, ordered by
+   (frame, id); n_per_frame[n_frames] receives the count for each frame. */
+int asl_detect_batch_u8(asl_detector *det, const uint8_t *const *frames, int n_frames, int channels,
+                        int w, int h, int stride, asl_detection *out, int max_out, int *n_per_frame,
+                        int *n_out);
+
+/* Same, frames already resident in HBM: frame i starts at d_frames + i*frame_pitch.
+   If K is non-NULL the per-tag PnP (asl_solve_pnp_batch) runs on the device in the same
+   submission and poses[i] belongs to out[i].  Results are written to HOST memory; the call
+   returns after the stream has drained. */
+int asl_detect_batch_device(asl_detector *det, const void *d_frames, int n_frames, int channels,
+                            int w, int h, int stride, size_t frame_pitch, void *stream,
+                            const double *K /*9, row-major, or NULL*/, const double *dist, int n_dist,
+                            double tag_size, asl_detection *out, asl_pose *poses, int max_out,
+                            int *n_per_frame, int *n_out);
+
+/* Replaces cv2.solvePnP(ITERATIVE) + cv2.Rodrigues for N tags at once (reference
+   tag_detector.py:30-52).  corners: N x 4 x 2 float32 (lb,rb,rt,lt), K row-major 3x3,
+   dist: n_dist in {0,4,5} coefficients (k1,k2,p1,p2[,k3]).  All pointers are host memory. */
+int asl_solve_pnp_batch(asl_detector *det, const float *corners, const double *K, const double *dist,
+                        int n_dist, double tag_size, double *rvec /*N x 3*/, double *tvec /*N x 3*/,
+                        double *T /*N x 16*/, uint8_t *ok /*N*/, int N);
+
+/* Pose-graph Gauss-Newton back-end (NOT in the reference: slam_graph.py:72-76 is a stub).
+   Unknowns: n_cams camera poses and n_tags tag poses (world<-x 4x4, row-major, updated in
+   place); tag `fixed_tag` is held at its input value and defines the world frame.
+   Observation k: camera obs_cam[k] saw tag obs_tag[k] with pixel corners obs_corners[k] (4x2).
+   Residual: the 8 pixel reprojection errors of the tag's 4 corners.  Runs `iters`
+   Levenberg-Marquardt steps on the device; stats[0] = initial cost, stats[1] = final cost,
+   stats[2] = iterations accepted. */
+int asl_gn_solve(asl_detector *det, int n_cams, int n_tags, int n_obs, const int32_t *obs_cam,
+                 const int32_t *obs_tag, const double *obs_corners, const double *K, double tag_size,
+                 int fixed_tag, double *cam_T /*n_cams x 16*/, double *tag_T /*n_tags x 16*/, int iters,
+                 double *stats /*3*/);
+
+/* Introspection for the parity tests: copy an intermediate buffer of the LAST batch to host.
+   what: 0 = decimated gray (u8, B*sh*sw)     1 = threshold image (u8, B*sh*sw)
+         2 = component labels (u32, B*sh*sw)  3 = component sizes by label (u32, B*sh*sw)
+         4 = candidate quads (asl_debug_quad, count via *n_items)
+         5 = stage counters (int64[16]: frames, sw, sh, clusters, points, quads, detections, ...)
+   bytes = capacity of dst; *n_items = number of elements written. */
+typedef struct {
+    double p[4][2]; /* decimated-image pixel coordinates, before the full-resolution rescale */
+    uint64_t cluster;
+    int32_t frame;
+    int32_t reversed_border;
+} asl_debug_quad;
+int asl_debug_fetch(asl_detector *det, int what, void *dst, size_t bytes, size_t *n_items);
+
+/* Time of each stage of the last batch in milliseconds (HIP events on the detector's stream):
+   names[i] / ms[i], i < *n. */
+int asl_stage_times(asl_detector *det, const char **names, float *ms, int max_n, int *n);
+/* Enable/disable per-stage event timing (adds a few events per batch; off by default). */
+int asl_set_profiling(asl_detector *det, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
