@@ -52,6 +52,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AslError("libaprilslam.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'`"
                        % LIB_PATH)
+    # ONE HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1, and a
+    # second runtime initialised in the same process cannot see the GPU.  Importing torch first makes
+    # libaprilslam.so's NEEDED "libamdhip64.so.7" resolve to the copy torch already loaded (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, dp, u8p = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8)
     L.asl_last_error.restype = C.c_char_p
@@ -201,8 +208,8 @@ class Detector:
         check(self._L.asl_set_profiling(self._h, 1 if on else 0))
 
     def stage_times(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
         n = C.c_int()
-        check(self._L.asl_stage_times(self._h, names, ms, 16, C.byref(n)))
+        check(self._L.asl_stage_times(self._h, names, ms, 32, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}

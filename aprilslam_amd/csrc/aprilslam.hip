@@ -57,7 +57,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-#define MAX_STAGES 16
+#define MAX_STAGES 24
 
 struct asl_detector {
     int device = 0;
@@ -253,43 +253,50 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     int twx = (g.sw + TILESZ - 1) / TILESZ, thx = (g.sh + TILESZ - 1) / TILESZ;
     unsigned int B = (unsigned int)g.nframes;
     d->nev = 0;
+    STAGE("memset");
     HIPCHK(hipMemsetAsync(d->counters.p, 0, sizeof(long long) * CNT__N, st));
     HIPCHK(hipMemsetAsync(d->sizes.p, 0, sizeof(unsigned int) * B * g.npix, st));
 
-    STAGE("threshold");
+    STAGE("k_decimate_minmax");
     hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
+    STAGE("k_threshold");
     hipLaunchKernelGGL(k_threshold, dim3((twx + 63) / 64, (g.sh + 3) / 4, B), blk, 0, st, d->dgray.p, g, d->tmin.p, d->tmax.p, d->thresh.p);
 
-    STAGE("components");
+    STAGE("k_cc_init");
     dim3 pgrid((g.sw + 63) / 64, (g.sh + 3) / 4, B);
     hipLaunchKernelGGL(k_cc_init, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
+    STAGE("k_cc_merge");
     hipLaunchKernelGGL(k_cc_merge, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
+    STAGE("k_cc_flatten");
     hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
 
-    STAGE("clusters");
+    STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots);
+    STAGE("k_cluster_count");
     hipLaunchKernelGGL(k_cluster_count, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hstats.p,
                        d->nslots - 1, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
+    STAGE("k_cluster_filter");
     hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots, g,
                        tag_width, d->fam.reversed_border ? 1 : 0, d->fam.reversed_border ? 0 : 1, d->clusters.p,
                        d->slot_cluster.p, d->max_clusters, d->max_points, d->counters.p);
+    STAGE("k_cluster_scatter");
     hipLaunchKernelGGL(k_cluster_scatter, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->nslots - 1,
                        d->slot_cluster.p, d->clusters.p, d->points.p);
 
-    STAGE("quads");
+    STAGE("k_fit_quads");
     unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 4096u);
     hipLaunchKernelGGL(k_fit_quads, dim3(qgrid), dim3(QF_THREADS), QF_LDS_BYTES, st, d->clusters.p, d->counters.p, d->max_clusters,
                        d->points.p, d->dgray.p, g, tag_width, d->scratch.p, d->quads.p);
 
-    STAGE("decode");
+    STAGE("k_decode");
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
     hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
                        d->maxhamming, d->refine, d->dets.p, d->max_dets, d->counters.p);
 
     if (cam) {
-        STAGE("pnp");
+        STAGE("k_pnp_dets");
         hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + 63) / 64), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam);
     }
     if (d->profiling && d->nev <= MAX_STAGES) HIPCHK(hipEventRecord(d->ev[d->nev], st));

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the AprilTag hot path at 1280x720, 20 tags/frame
+(BASELINE.json configs[1]: detection + batched PnP on one MI355X), frames resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+A step = one batch of B synthetic BGR frames through asl_detect_batch_device (threshold ->
+components -> clusters -> quads -> decode -> PnP, detections and poses copied back, host
+dedup/sort).  For N > 1 every rank runs its own stream of B frames per step (weak scaling) and
+the ranks all-gather their observation records (RCCL) inside the timed region.
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NTAGS = 1280, 720, 20
+TAG_OUTER, TAG_INNER = 18.0, 10.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_frames(n_distinct, seed=20250620 + 1):
+    """n_distinct frames of one seeded 20-tag scene seen from a smooth camera trajectory."""
+    from aprilslam_amd import synth
+    rng = np.random.default_rng(seed)
+    tags = synth.random_scene(W, H, NTAGS, rng, tag_size_outer=TAG_OUTER)
+    frames = []
+    for i in range(n_distinct):
+        a = 2 * np.pi * i / max(n_distinct, 1)
+        pos = (1.5 * np.cos(a), 1.0 * np.sin(a), 2.0 * np.sin(2 * a))
+        rot = (0.6 * np.sin(a), 0.8 * np.cos(a), 0.5 * np.sin(3 * a))
+        f, _ = synth.render_frame(W, H, tags, TAG_OUTER, cam_position=pos, cam_rotation_deg=rot)
+        frames.append(f)
+    return np.stack(frames)
+
+
+def algorithmic_bytes(kernel, w, h, ch, f):
+    """Compulsory HBM bytes of one launch PER FRAME (reads + writes of the kernel's operands,
+    each counted once).  DESIGN.md section 'Kernels' derives these."""
+    sw, sh = 1 + (w - 1) // f, 1 + (h - 1) // f
+    npix = sw * sh
+    ntile = (sw // 4) * (sh // 4)
+    full = w * h * ch
+    table = {
+        "k_decimate_minmax": full + npix + 2 * ntile,
+        "k_threshold": npix + 2 * ntile + npix,
+        "k_cc_init": npix + 4 * npix,
+        "k_cc_merge": npix + 4 * npix,
+        "k_cc_flatten": npix + 4 * npix + 4 * npix + 4 * npix,
+        "k_cluster_count": npix + 4 * npix + 4 * npix,
+        "k_cluster_scatter": npix + 4 * npix + 4 * npix,
+        "memset": 4 * npix,
+    }
+    return table.get(kernel)
+
+
+def stage_algorithmic_read_bytes(w, h, ch, f):
+    """R = W*H*(1 + 5/d^2) (+ 2*W*H when BGR->gray is inside the timed region)."""
+    return w * h * (1 + 5.0 / (f * f)) + (2 * w * h if ch == 3 else 0)
+
+
+def cpu_baseline(frames, K, budget_s=12.0):
+    """The CPU restatement (oracle/, 1 thread) timed on this host on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from aprilslam_amd.families import get_family
+    fam = get_family()
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        fr = frames[n % len(frames)]
+        dets = O.detect_bgr(fr, fam)
+        if dets:
+            O.solve_pnp(np.stack([d["corners"] for d in dets]), K, np.zeros(4), TAG_INNER)
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp, 1 thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct rendered frames (tiled to --batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from aprilslam_amd import _lib, synth
+    from aprilslam_amd import dist as adist
+
+    K = synth.camera_matrix(W, H)
+    distinct = make_frames(args.distinct, seed=20250620 + 1 + rank)  # each rank = its own stream
+    B = args.batch
+    reps = (B + len(distinct) - 1) // len(distinct)
+    d_frames = torch.from_numpy(distinct).to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
+    det = _lib.Detector("tagStandard41h12", device=local_rank)
+    det.set_profiling(True)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        dets, poses, npf = det.detect_device(d_frames.data_ptr(), B, 3, W, H, stream=stream, K=K, dist=np.zeros(4), tag_size=TAG_INNER)
+        if world > 1:
+            obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4)
+            adist.all_gather_observations(obs, device=dev)
+        return dets, npf
+
+    for _ in range(args.warmup):
+        dets, npf = step()
+    n_found = int(len(dets))
+
+    kernel_ms = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in det.stage_times().items():
+            kernel_ms.setdefault(k, []).append(v)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
+        kernels_only = {k: v for k, v in avg.items() if k.startswith("k_")}
+        dom = max(kernels_only, key=kernels_only.get)
+        ab = algorithmic_bytes(dom, W, H, 3, 2)
+        roof = None
+        if ab is not None:
+            achieved = ab * B / (avg[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
+                    "algorithmic_bytes_per_frame": ab}
+        else:
+            # per-cluster / per-quad kernels: latency- and occupancy-bound work on L2-resident slabs; their
+            # compulsory HBM bytes are the boundary-point keys (8 B read) plus the moment slab (64 B written)
+            pts = 8.0 * det.debug_counters()[4] / B
+            achieved = (pts * 9) * B / (avg[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
+                    "algorithmic_bytes_per_frame": pts * 9}
+        seg = sum(avg.get(k, 0.0) for k in ("memset", "k_decimate_minmax", "k_threshold", "k_cc_init", "k_cc_merge", "k_cc_flatten",
+                                             "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_cluster_scatter"))
+        seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
+        seg_gbs = seg_bytes * B / (seg * 1e-3) / 1e9 if seg > 0 else 0.0
+        line = {
+            "metric": "frames/sec at 1280x720, 20 tags/frame (detection + batched PnP)",
+            "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/f64",
+            "data": "synthetic: %d distinct rendered frames of a seeded 20-tag scene tiled to %d frames per step, resident in HBM" % (len(distinct), B),
+            "config": {"workload": "configs[1]: 1280x720 BGR stream, 20 tags/frame, detect + PnP", "batch_frames": B,
+                       "decimate": 2, "tags_found_per_batch": n_found, "parallelism": "1 stream per GPU"},
+            "roofline": roof,
+            "stage_threshold_segmentation": {"ms_per_batch": seg, "algorithmic_read_bytes_per_frame": seg_bytes,
+                                             "achieved_GBs": seg_gbs, "frac_of_hbm_peak": seg_gbs / HBM_PEAK_GBS},
+            "kernel_ms_per_batch": avg,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(distinct, K)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

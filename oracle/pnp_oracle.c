@@ -51,7 +51,7 @@ static void rot_to_rvec(const double *R, double r[3])
     double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1 ? 1 : (c < -1 ? -1 : c);
-    double theta = acos(c);
+    double theta = atan2(s, c);
     if (s < 1e-5) {
         if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
         double t;
@@ -286,7 +286,7 @@ static int pnp_one(const double *img /*4x2*/, const cam_t *c, double tag_size, d
         double prev = cost;
         cost = residuals(c, R, t, obj, img, res, J);
         double scale = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + 1;
-        if (step_norm < 1e-13 * scale || prev - cost < 1e-18 * (1 + prev)) break;
+        if (step_norm < 1e-10 * scale || prev - cost < 1e-15 * (1 + prev)) break;
     }
     nearest_rotation(R, R);
     rot_to_rvec(R, rvec);

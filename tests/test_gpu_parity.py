@@ -1,0 +1,130 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle, stage by stage.
+
+Bars: bit-exact for every integer/byte/index product (decimated gray, threshold image, component
+labels and sizes, tag ids, hamming, corner order); float products (quad corners, detection corners,
+margin) are computed with the same IEEE operations in the same order as the oracle, so they are
+held to 1e-9 px absolute (observed: identical)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from aprilslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CORNER_TOL = 1e-9
+
+
+def scene_frame(width, height, ntags, seed, noise=0.0):
+    rng = np.random.default_rng(seed)
+    tags = synth.random_scene(width, height, ntags, rng)
+    frame, gt = synth.render_frame(width, height, tags, 18.0, noise_sigma=noise, rng=rng)
+    return frame, gt
+
+
+def check_stages(det, frames, family, decimate=2):
+    """frames: (B,H,W,3) or (B,H,W) uint8"""
+    dets, npf = det.detect_host(frames, channels=1 if frames.ndim == 3 else None)
+    dgray = det.debug_image(0)
+    thresh = det.debug_image(1)
+    labels = det.debug_image(2)
+    sizes = det.debug_image(3)
+    quads = det.debug_quads()
+    B = frames.shape[0]
+    start = 0
+    for b in range(B):
+        gray = O.bgr2gray(frames[b]) if frames.ndim == 4 else frames[b]
+        dec = O.decimate(gray, decimate)
+        assert np.array_equal(dgray[b], dec), "decimated gray differs (frame %d)" % b
+        th = O.threshold(dec)
+        assert np.array_equal(thresh[b], th), "threshold image differs (frame %d)" % b
+        lab, sz = O.connected_components(th)
+        assert np.array_equal(labels[b], lab), "component labels differ (frame %d)" % b
+        roots = lab.ravel() == np.arange(lab.size, dtype=np.uint32)
+        assert np.array_equal(sizes[b].ravel()[roots], sz.ravel()[roots]), "component sizes differ (frame %d)" % b
+        pts = O.gradient_clusters(th, lab, sz)
+        oq = O.fit_quads(dec, pts, family, decimate)
+        gq = quads[quads["frame"] == b]
+        assert [int(q["cluster"]) for q in gq] == [int(q["cluster"]) for q in oq], "quad clusters differ (frame %d)" % b
+        for a, o in zip(gq, oq):
+            assert np.abs(a["p"] - o["p"]).max() <= CORNER_TOL, (b, a["p"], o["p"])
+        ref = O.detect_gray(gray, family, decimate)
+        mine = dets[start:start + npf[b]]
+        start += npf[b]
+        assert [int(d["id"]) for d in mine] == [r["id"] for r in ref], "ids differ (frame %d)" % b
+        for d, r in zip(mine, ref):
+            assert int(d["hamming"]) == r["hamming"]
+            assert np.abs(d["corners"] - r["corners"]).max() <= CORNER_TOL, (b, d["corners"], r["corners"])
+            assert np.abs(d["center"] - r["center"]).max() <= CORNER_TOL
+            assert abs(float(d["margin"]) - r["margin"]) <= 1e-4
+    return dets, npf
+
+
+def test_default_scene_stage_parity(gpu_detector, family):
+    sc = synth.default_scene()
+    # camera nudged off the origin so that edges are not pixel-aligned; tags 3 and 4 are outside the 45 deg view
+    frame, _ = synth.render_frame(1000, 1000, sc["tags"], 18.0, cam_position=(-0.7, -0.4, 1.1), cam_rotation_deg=(0.5, -1.0, -0.7))
+    dets, npf = check_stages(gpu_detector, frame[None], family)
+    assert [int(d["id"]) for d in dets] == [0, 1, 2]
+
+
+@pytest.mark.parametrize("w,h,ntags,seed", [(1280, 720, 20, 1), (640, 480, 6, 2), (1001, 703, 8, 3), (322, 242, 2, 4)])
+def test_random_scene_stage_parity(gpu_detector, family, w, h, ntags, seed):
+    frame, _ = scene_frame(w, h, ntags, seed)
+    dets, npf = check_stages(gpu_detector, frame[None], family)
+    if (w, h) == (1280, 720):
+        assert len(dets) == ntags and sorted(int(d["id"]) for d in dets) == list(range(ntags))
+
+
+def test_noisy_batch_stage_parity(gpu_detector, family):
+    frames = np.stack([scene_frame(640, 360, 5, 100 + i, noise=3.0)[0] for i in range(4)])
+    check_stages(gpu_detector, frames, family)
+
+
+def test_gray_input_and_empty_frame(gpu_detector, family):
+    rng = np.random.default_rng(7)
+    frames = np.stack([np.zeros((240, 320), np.uint8), rng.integers(0, 256, (240, 320), dtype=np.uint8),
+                       np.full((240, 320), 200, np.uint8)])
+    dets, npf = check_stages(gpu_detector, frames, family)
+    assert npf[0] == 0 and npf[2] == 0
+
+
+def test_pnp_parity(gpu_detector, family):
+    frame, gt = scene_frame(1280, 720, 20, 11)
+    dets, _ = gpu_detector.detect_host(frame)
+    K = synth.camera_matrix(1280, 720)
+    corners = dets["corners"]
+    for dist in (np.zeros(4), np.array([0.05, -0.02, 0.001, -0.0005, 0.01])):
+        rv, tv, T, ok = gpu_detector.solve_pnp(corners, K, dist, 10.0)
+        orv, otv, oT, ook = O.solve_pnp(corners, K, dist, 10.0)
+        assert ok.all() and ook.all()
+        # float64 on both sides; libm sin/cos/atan2 differ in the last ulp between host and device
+        assert np.abs(tv - otv).max() < 1e-6 and np.abs(rv - orv).max() < 1e-7 and np.abs(T - oT).max() < 1e-6
+    # against analytic ground truth: <= 1 mm at 5.56 mm/unit, i.e. 0.18 units, is the north-star bar vs the
+    # reference; vs ground truth the detector's corner noise dominates, so only a loose sanity bound here
+    rv, tv, T, ok = gpu_detector.solve_pnp(corners, K, np.zeros(4), 10.0)
+    for d, t in zip(dets, T):
+        g = gt[int(d["id"])]
+        assert np.linalg.norm(t[:3, 3] - g[:3, 3]) < 0.02 * np.linalg.norm(g[:3, 3])
+
+
+def test_device_resident_batch_with_pose(gpu_detector, family):
+    import torch
+    frames = np.stack([scene_frame(1280, 720, 20, 200 + i)[0] for i in range(3)])
+    K = synth.camera_matrix(1280, 720)
+    t = torch.from_numpy(frames).to("cuda:0")
+    dets, poses, npf = gpu_detector.detect_device(t.data_ptr(), 3, 3, 1280, 720, K=K, dist=np.zeros(4), tag_size=10.0)
+    hd, hn = gpu_detector.detect_host(frames)
+    assert np.array_equal(npf, hn) and np.array_equal(dets["id"], hd["id"]) and np.array_equal(dets["corners"], hd["corners"])
+    rv, tv, T, ok = gpu_detector.solve_pnp(dets["corners"], K, np.zeros(4), 10.0)
+    assert np.array_equal(poses["tvec"], tv) and np.array_equal(poses["rvec"], rv) and poses["ok"].all()
+
+
+def test_errors_are_loud(gpu_detector):
+    from aprilslam_amd import _lib
+    with pytest.raises(_lib.AslError):
+        _lib.Detector("tag36h11")
+    with pytest.raises(_lib.AslError):
+        _lib.Detector("tagStandard41h12", decimate=1.5)
+    with pytest.raises(_lib.AslError):
+        _lib.Detector("tagStandard41h12", blur=0.8)
