@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaprilslam.so")
+LIB_PATH = os.environ.get("ASL_LIB") or os.path.join(_HERE, "libaprilslam.so")  # ASL_LIB: diagnostic builds only
 
 
 class AslError(RuntimeError):
@@ -38,7 +38,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_last_error", "asl_version", "asl_detect_gray_u8",
     "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_device", "asl_solve_pnp_batch", "asl_gn_solve",
-    "asl_debug_fetch", "asl_stage_times", "asl_set_profiling",
+    "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load():
     L.asl_debug_fetch.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.asl_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32, C.POINTER(i32)]
     L.asl_set_profiling.argtypes = [vp, i32]
+    L.asl_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     _lib = L
     return L
 
@@ -203,6 +204,11 @@ class Detector:
         n = C.c_size_t()
         check(self._L.asl_debug_fetch(self._h, 4, buf.ctypes.data, buf.nbytes, C.byref(n)))
         return buf[:n.value]
+
+    def phase_cycles(self, reset=True):
+        buf = (C.c_uint64 * 64)()
+        check(self._L.asl_debug_phase_cycles(self._h, buf, 1 if reset else 0))
+        return np.array(list(buf), dtype=np.uint64)
 
     def set_profiling(self, on=True):
         check(self._L.asl_set_profiling(self._h, 1 if on else 0))

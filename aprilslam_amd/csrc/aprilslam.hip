@@ -68,7 +68,7 @@ struct asl_detector {
     unsigned long long *d_codes = nullptr;
 
     // capacities (grow on overflow)
-    unsigned int hash_slots_per_frame = 8192;
+    unsigned int hash_slots_per_frame = 1024;
     unsigned int clusters_per_frame = 1024;
     unsigned int dets_per_frame = 256;
     double points_per_pixel = 0.5;
@@ -77,7 +77,7 @@ struct asl_detector {
     DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
     DevBuf<unsigned int> parent, sizes;
     DevBuf<unsigned long long> hkeys, points;
-    DevBuf<ClusterStat> hstats;
+    DevBuf<unsigned int> hcounts, class_lists;
     DevBuf<int> slot_cluster;
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
@@ -148,6 +148,8 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
         return fail(ASL_EDEVICE, "hipMemcpy(code book) failed");
     }
     d->fam.codes = d->d_codes;
+    // class-2 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS2_CAP);
     *out = d;
     return ASL_OK;
 }
@@ -157,7 +159,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
-    d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hstats.release();
+    d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
@@ -225,7 +227,8 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->parent.ensure(total);
     bad |= d->sizes.ensure(total);
     bad |= d->hkeys.ensure(d->nslots);
-    bad |= d->hstats.ensure(d->nslots);
+    bad |= d->hcounts.ensure(d->nslots);
+    bad |= d->class_lists.ensure((size_t)NCLASSES * d->max_clusters);
     bad |= d->slot_cluster.ensure(d->nslots);
     bad |= d->clusters.ensure(d->max_clusters);
     bad |= d->quads.ensure(d->max_clusters);
@@ -271,24 +274,38 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
 
     STAGE("k_hash_clear");
-    hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots);
+    hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_cluster_count");
-    hipLaunchKernelGGL(k_cluster_count, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hstats.p,
+    dim3 tgrid((g.sw + 15) / 16, (g.sh + 15) / 16, B);  // wave = 16x4 pixel tile
+    hipLaunchKernelGGL(k_cluster_count, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p,
                        d->nslots - 1, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");
-    hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hstats.p, d->nslots, g,
-                       tag_width, d->fam.reversed_border ? 1 : 0, d->fam.reversed_border ? 0 : 1, d->clusters.p,
-                       d->slot_cluster.p, d->max_clusters, d->max_points, d->counters.p);
+    hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots, g,
+                       d->clusters.p, d->slot_cluster.p, d->class_lists.p, d->max_clusters, d->max_points, d->counters.p);
     STAGE("k_cluster_scatter");
-    hipLaunchKernelGGL(k_cluster_scatter, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->nslots - 1,
+    hipLaunchKernelGGL(k_cluster_scatter, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->nslots - 1,
                        d->slot_cluster.p, d->clusters.p, d->points.p);
 
-    STAGE("k_fit_quads");
-    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 4096u);
-    hipLaunchKernelGGL(k_fit_quads, dim3(qgrid), dim3(QF_THREADS), QF_LDS_BYTES, st, d->clusters.p, d->counters.p, d->max_clusters,
-                       d->points.p, d->dgray.p, g, tag_width, d->scratch.p, d->quads.p);
+    // one launch per size class; each walks its own cluster list (grid-stride)
+    const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
+    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 16384u);
+    STAGE("k_fit_quads<0>");
+    hipLaunchKernelGGL((k_fit_quads<64, true>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
+                       d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+    STAGE("k_fit_quads<1>");
+    hipLaunchKernelGGL((k_fit_quads<64, true>), dim3(qgrid), dim3(64), 64 * CLASS1_CAP, st, d->clusters.p,
+                       d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+    STAGE("k_fit_quads<2>");
+    hipLaunchKernelGGL((k_fit_quads<256, true>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
+                       d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+    STAGE("k_fit_quads<3>");
+    hipLaunchKernelGGL((k_fit_quads<256, false>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
+                       d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, 0, d->points.p, d->dgray.p, g,
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
 
     STAGE("k_decode");
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
@@ -578,6 +595,18 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
     default:
         return fail(ASL_EINVAL, "unknown debug item %d", what);
     }
+}
+
+extern "C" int asl_debug_phase_cycles(asl_detector *d, unsigned long long *out64, int reset)
+{
+    if (!d || !out64) return fail(ASL_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 64));
+    if (reset) {
+        unsigned long long z[64] = {0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z));
+    }
+    return ASL_OK;
 }
 
 #include "gn_host.inc"

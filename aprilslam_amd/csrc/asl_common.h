@@ -12,6 +12,11 @@
 #define COS_CRITICAL_RAD 0.984807753012208 /* cos(10 deg) */
 #define HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define HASH_MAX_PROBE 512
+#define NCLASSES 4
+// size classes of the quad fit: points <= 128, <= 256, <= 1024 (all-LDS), larger (global slab)
+#define CLASS0_CAP 128
+#define CLASS1_CAP 256
+#define CLASS2_CAP 1024
 
 // Geometry of one batch, passed by value to every kernel.
 struct Geom {
@@ -26,22 +31,13 @@ struct Geom {
     size_t npix;         // sw*sh
 };
 
-// Per-cluster statistics gathered while counting boundary points (hash table payload).
-struct ClusterStat {
-    unsigned int count;
-    unsigned int xmin, ymin, xmax, ymax;  // half-pixel fixed point
-    int sgx, sgy;                         // sum of gx, gy
-    long long sxg;                        // sum of x*gx + y*gy
-};
-
-// A cluster that survived the pre-filter and will be fitted.
+// A cluster that survived the size pre-filter and will be fitted.
 struct ClusterRec {
     uint64_t key;        // (frame << 48) | (hi << 24) | lo
     unsigned int offset; // first point in the point pool
     unsigned int count;
     unsigned int fill;   // scatter cursor
-    int reversed;        // border polarity: 1 = white inside black
-    float cx, cy;        // bounding-box centre + fixed jitter
+    unsigned int pad;
 };
 
 struct QuadRec {
@@ -86,8 +82,30 @@ enum {
     CNT_OVERFLOW_DETS,
     CNT_NQUADS,
     CNT_TOTAL_EMITTED,
+    CNT_CLASS0,  // clusters per size class (lists consumed by the fit kernels)
+    CNT_CLASS1,
+    CNT_CLASS2,
+    CNT_CLASS3,
     CNT__N = 16
 };
+
+// Diagnostic build only (-DASL_PHASE_TIMING): per-phase shader-clock sums, one stamp per block.
+// The shipped library compiles these to nothing.
+__device__ unsigned long long g_phase_cycles[64];
+#ifdef ASL_PHASE_TIMING
+#define PHASE_INIT() long long ph_t__ = clock64()
+#define PHASE(k)                                                                      \
+    do {                                                                              \
+        if (threadIdx.x == 0) {                                                       \
+            long long now__ = clock64();                                              \
+            atomicAdd(&g_phase_cycles[k], (unsigned long long)(now__ - ph_t__));      \
+            ph_t__ = now__;                                                           \
+        }                                                                             \
+    } while (0)
+#else
+#define PHASE_INIT() do {} while (0)
+#define PHASE(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ int gray_at(const uint8_t *frame, const Geom &g, int x, int y)
 {

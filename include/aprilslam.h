@@ -137,6 +137,10 @@ int asl_stage_times(asl_detector *det, const char **names, float *ms, int max_n,
 /* Enable/disable per-stage event timing (adds a few events per batch; off by default). */
 int asl_set_profiling(asl_detector *det, int enabled);
 
+/* Diagnostic builds only (-DASL_PHASE_TIMING): summed shader-clock cycles per kernel phase
+   (64 counters); all zeros in the shipped library. */
+int asl_debug_phase_cycles(asl_detector *det, unsigned long long *out64, int reset);
+
 #ifdef __cplusplus
 }
 #endif
