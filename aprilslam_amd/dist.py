@@ -52,7 +52,8 @@ def all_gather_observations(local_obs, device=None):
         t = t.to(device)
     world = dist.get_world_size()
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
+    # one flat all-gather; the output rows are views of one contiguous block
+    dist.all_gather([out[r] for r in range(world)], t)
     return out.cpu().numpy()
 
 

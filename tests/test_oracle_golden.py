@@ -1,0 +1,162 @@
+"""Pins the CPU oracle (oracle/) against everything the reference holds for this path:
+  * tests/golden/tag_grids.json   -- the 9x9 cell grids of reference assets/tags/tag{0..4}.png
+  * tests/golden/reference_run.json -- numbers of the reference's committed run (CSV row 2, log lines 26-27)
+and checks the oracle's own stage invariants on seeded inputs (the GPU path is then compared with the
+oracle bit for bit in test_gpu_parity.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from aprilslam_amd import synth
+from aprilslam_amd.slam import SLAM
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GRIDS = json.load(open(os.path.join(HERE, "golden", "tag_grids.json")))["grids"]
+RUN = json.load(open(os.path.join(HERE, "golden", "reference_run.json")))
+
+
+class _Log:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, m):
+        self.lines.append(str(m))
+
+
+def test_codes_0_to_4_match_reference_tag_images(family):
+    for tid, rows in GRIDS.items():
+        g = family.grid(int(tid))
+        got = ["".join("." if v else "#" for v in r) for r in g]
+        assert got == rows, "tag %s grid differs from the reference image" % tid
+
+
+def test_code_stride_of_published_generator(family):
+    # the five pinned codes step by the generator prime 982451653 (mod 2^41)
+    c = [int(x) for x in family.codes[:5]]
+    assert c[0] == 0x1BD8A64AD10
+    assert all((c[i + 1] - c[i]) % (1 << 41) == 982451653 for i in range(4))
+
+
+@pytest.mark.parametrize("tid", [0, 1, 2, 3, 4])
+def test_oracle_decodes_reference_tags_in_all_rotations(family, tid):
+    """Render each reference tag fronto-parallel at 4 in-plane rotations: id exact, hamming 0, and the
+    lb-rb-rt-lt corner order follows the tag (tag_detector.py:32-38)."""
+    for roll in (0.0, 90.0, 180.0, 270.0):
+        tag = {"id": tid, "position": [1.3, -0.8, -60.0], "rotation": [3.0, -4.0, roll + 2.0]}
+        frame, gt = synth.render_frame(640, 480, [tag], 18.0)
+        dets = O.detect_bgr(frame, family)
+        assert [d["id"] for d in dets] == [tid]
+        d = dets[0]
+        assert d["hamming"] == 0
+        K = synth.camera_matrix(640, 480)
+        T = gt[tid]
+        for k, (X, Y) in enumerate([(-5, -5), (5, -5), (5, 5), (-5, 5)]):  # lb, rb, rt, lt in the tag frame
+            P = T[:3, :3] @ np.array([X, Y, 0.0]) + T[:3, 3]
+            uv = np.array([K[0, 0] * P[0] / P[2] + K[0, 2], K[1, 1] * P[1] / P[2] + K[1, 2]])
+            assert np.linalg.norm(d["corners"][k] - uv) < 1.0, (roll, k, d["corners"][k], uv)
+
+
+def _run_default_scene(family, cam_position, cam_rotation):
+    sc = synth.default_scene()
+    W, H = sc["display_width"], sc["display_height"]
+    frame, gt = synth.render_frame(W, H, sc["tags"], sc["tag_size_outer"] * sc["size_scale"],
+                                   cam_position=cam_position, cam_rotation_deg=cam_rotation)
+    dets = O.detect_bgr(frame, family)
+    K = synth.camera_matrix(W, H, sc["fov_y"])
+    tag_size = sc["tag_size_inner"] * sc["size_scale"]
+    rv, tv, T, ok = O.solve_pnp(np.stack([d["corners"] for d in dets]), K, np.zeros(4), tag_size)
+    assert ok.all()
+    log = _Log()
+    slam = SLAM(log, {"camera_matrix": K, "dist_coeffs": np.zeros((4, 1))}, detector=object())
+    pose = slam.process_observations([d["id"] for d in dets], T)
+    lens = {int(l.split()[2]): float(l.rsplit("=", 1)[1]) for l in log.lines if l.startswith("Tag ID")}
+    return dets, pose, slam, lens, np.linalg.inv(gt[0])
+
+
+def test_default_scene_matches_reference_run(family):
+    """Camera at the origin of the reference's default scene (config/sim_settings.json): the committed run saw
+    3 nodes (tags 0,1,2), pose (-0.004, 0.004, 50.02) and world-translation lengths 76.34 / 45.47.  The author's
+    OpenGL rasteriser cannot be reproduced, so these are tolerance-level checks.  With every tag edge exactly
+    pixel-aligned the edge refinement's 0.25 px search grid sits on a knife edge (a 0.03 px tilt of the first
+    fit flips half of the samples by one step), which costs ~1 deg / ~1 unit here; the reference's own logged
+    trajectory shows errors of the same size (RMSE 1.8 units, tests/golden/reference_run.json)."""
+    dets, pose, slam, lens, gt_pose = _run_default_scene(family, (0, 0, 0), (0, 0, 0))
+    ref = RUN["csv_row_camera_at_origin"]
+    assert [d["id"] for d in dets] == [0, 1, 2] and all(d["hamming"] == 0 for d in dets)
+    assert len(slam.graph.get_nodes()) == ref["num_nodes"] and slam.coordinate_id == 0
+    assert np.linalg.norm(pose[:3, 3] - np.array(ref["gt_xyz"])) < RUN["csv_error_stats_sim_units"]["translation_rmse"]
+    assert abs(pose[2, 3] - ref["est_xyz"][2]) < 0.1
+    assert abs(slam.average_distance_to_nodes() - ref["avg_distance"]) < 0.5
+    lg = RUN["log_world_translation_length"]
+    assert abs(lens[1] - lg["tag1_analytic"]) < 1.5 and abs(lens[2] - lg["tag2_analytic"]) < 1.5
+
+
+def test_default_scene_generic_view_is_accurate(family):
+    """Same scene seen from a pose whose edges are not pixel-aligned: the reference's best-case accuracy
+    (0.02 units at the origin, slam_clustered_data.csv:2) is reproduced."""
+    dets, pose, slam, lens, gt_pose = _run_default_scene(family, (-0.7, -0.4, 1.1), (0.5, -1.0, -0.7))
+    assert [d["id"] for d in dets] == [0, 1, 2]
+    assert np.linalg.norm(pose[:3, 3] - gt_pose[:3, 3]) < 0.05
+    assert np.linalg.norm(pose[:3, :3] - gt_pose[:3, :3]) < 2e-3
+    lg = RUN["log_world_translation_length"]
+    assert abs(lens[1] - lg["tag1_analytic"]) < 0.3 and abs(lens[2] - lg["tag2_analytic"]) < 0.3
+
+
+def test_gray_is_cv2_fixed_point():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    g = O.bgr2gray(img)
+    b, gg, r = [img[..., i].astype(np.int64) for i in range(3)]
+    assert np.array_equal(g, ((b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8))
+    assert O.bgr2gray(np.full((1, 1, 3), 255, np.uint8))[0, 0] == 255
+    assert O.bgr2gray(np.array([[[128, 0, 128]]], np.uint8))[0, 0] == 53  # the renderer's purple background
+
+
+def test_threshold_and_components_invariants():
+    rng = np.random.default_rng(1)
+    im = (rng.integers(0, 256, (37, 53)) // 64 * 64).astype(np.uint8)
+    im[5:20, 8:30] = 250
+    th = O.threshold(im)
+    assert set(np.unique(th)) <= {0, 127, 255}
+    lab, sz = O.connected_components(th)
+    flat = lab.ravel()
+    # canonical label = smallest raster index of the component; sizes add up; a label never crosses values
+    assert np.all(flat <= np.arange(flat.size))
+    assert np.all(flat[flat] == flat)
+    assert sz.ravel()[np.unique(flat)].sum() == flat.size
+    assert np.all(th.ravel()[flat] == th.ravel())
+    assert np.all(sz.ravel()[flat[th.ravel() == 127]] == 1)
+    # flat image: no contrast anywhere -> all 127
+    assert np.all(O.threshold(np.full((16, 16), 77, np.uint8)) == 127)
+
+
+def test_ragged_sizes_and_decimate():
+    rng = np.random.default_rng(2)
+    for (h, w) in [(9, 11), (8, 8), (13, 30)]:
+        im = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        d = O.decimate(im, 2)
+        assert d.shape == (1 + (h - 1) // 2, 1 + (w - 1) // 2) and np.array_equal(d, im[::2, ::2])
+        th = O.threshold(d)
+        assert th.shape == d.shape
+
+
+def test_pnp_recovers_exact_pose():
+    rng = np.random.default_rng(3)
+    K = synth.camera_matrix(1280, 720)
+    for _ in range(20):
+        tag = {"id": 0, "position": list(rng.uniform([-20, -10, -120], [20, 10, -40])), "rotation": list(rng.uniform(-40, 40, 3))}
+        T = synth.camera_from_tag(tag["position"], tag["rotation"])
+        c = []
+        for (X, Y) in [(-5, -5), (5, -5), (5, 5), (-5, 5)]:
+            P = T[:3, :3] @ np.array([X, Y, 0.0]) + T[:3, 3]
+            c.append([K[0, 0] * P[0] / P[2] + K[0, 2], K[1, 1] * P[1] / P[2] + K[1, 2]])
+        rv, tv, To, ok = O.solve_pnp(np.array([c]), K, np.zeros(4), 10.0)
+        assert ok[0]
+        # corners pass through float32 (tag_detector.py:32): ~1e-4 px -> ~1e-4 units at these depths
+        assert np.abs(To[0] - T).max() < 5e-3
+        R = np.zeros(9)
+        O.lib().aso_rodrigues(rv[0].ctypes.data_as(O.C.POINTER(O.C.c_double)), R.ctypes.data_as(O.C.POINTER(O.C.c_double)))
+        assert np.abs(R.reshape(3, 3) - To[0][:3, :3]).max() < 1e-12
