@@ -130,7 +130,7 @@ class Detector:
         stride = W * ch
         ptrs = (C.c_void_p * B)(*[a[i].ctypes.data for i in range(B)])
         cap = B * max_per_frame
-        out = np.zeros(cap, dtype=DET_DTYPE)
+        out = np.empty(cap, dtype=DET_DTYPE)
         npf = (C.c_int * B)()
         n = C.c_int()
         check(self._L.asl_detect_batch_u8(self._h, ptrs, B, ch, W, H, stride, out.ctypes.data, cap, npf, C.byref(n)))
@@ -140,13 +140,13 @@ class Detector:
 
     # -- frames resident in HBM ---------------------------------------------------------
     def detect_device(self, data_ptr, n_frames, channels, width, height, stride=None, frame_pitch=None, stream=0,
-                      K=None, dist=None, tag_size=0.0, max_per_frame=256, want_poses=None):
+                      K=None, dist=None, tag_size=0.0, max_per_frame=64, want_poses=None):
         stride = stride or width * channels
         frame_pitch = frame_pitch or stride * height
         cap = n_frames * max_per_frame
-        out = np.zeros(cap, dtype=DET_DTYPE)
+        out = np.empty(cap, dtype=DET_DTYPE)
         want_poses = (K is not None) if want_poses is None else want_poses
-        poses = np.zeros(cap if want_poses else 0, dtype=POSE_DTYPE)
+        poses = np.empty(cap if want_poses else 0, dtype=POSE_DTYPE)
         npf = (C.c_int * n_frames)()
         n = C.c_int()
         dp = C.POINTER(C.c_double)
@@ -165,7 +165,8 @@ class Detector:
                                               out.ctypes.data, poses.ctypes.data if want_poses else None, cap, npf,
                                               C.byref(n)))
         if n.value > cap:
-            raise AslError("more than %d detections per frame on average; raise max_per_frame" % max_per_frame)
+            return self.detect_device(data_ptr, n_frames, channels, width, height, stride, frame_pitch, stream, K, dist,
+                                      tag_size, max_per_frame=(n.value + n_frames - 1) // n_frames + 1, want_poses=want_poses)
         return out[:n.value], (poses[:n.value] if want_poses else None), np.array(list(npf), dtype=np.int64)
 
     def solve_pnp(self, corners, K, dist, tag_size):

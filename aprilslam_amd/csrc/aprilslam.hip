@@ -77,7 +77,9 @@ struct asl_detector {
     DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
     DevBuf<unsigned int> parent, sizes;
     DevBuf<unsigned long long> hkeys, points;
-    DevBuf<unsigned int> hcounts, class_lists;
+    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor;
+    DevBuf<unsigned long long> stage_rec;
+    unsigned int stage_cap = 0;  // staged points per frame
     DevBuf<int> slot_cluster;
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
@@ -93,7 +95,8 @@ struct asl_detector {
     Geom last{};
     unsigned int nslots = 0, max_clusters = 0, max_points = 0, max_dets = 0;
     long long last_counters[CNT__N] = {0};
-    std::vector<DetRec> host_dets;
+    DetRec *host_dets = nullptr;  // pinned
+    size_t host_dets_cap = 0;
 
     // profiling
     int profiling = 0;
@@ -159,11 +162,12 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
-    d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release();
+    d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->d_codes) (void)hipFree(d->d_codes);
+    if (d->host_dets) (void)hipHostFree(d->host_dets);
     for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
     delete d;
 }
@@ -233,6 +237,10 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->clusters.ensure(d->max_clusters);
     bad |= d->quads.ensure(d->max_clusters);
     bad |= d->points.ensure(d->max_points);
+    d->stage_cap = (unsigned int)((double)g.npix * d->points_per_pixel) + 1024u;
+    bad |= d->stage_rec.ensure((size_t)B * d->stage_cap);
+    bad |= d->stage_pos.ensure((size_t)B * d->stage_cap);
+    bad |= d->frame_cursor.ensure(B);
     bad |= d->scratch.ensure((size_t)d->max_points * 8);
     bad |= d->dets.ensure(d->max_dets);
     bad |= d->counters.ensure(CNT__N);
@@ -258,34 +266,35 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     d->nev = 0;
     STAGE("memset");
     HIPCHK(hipMemsetAsync(d->counters.p, 0, sizeof(long long) * CNT__N, st));
-    HIPCHK(hipMemsetAsync(d->sizes.p, 0, sizeof(unsigned int) * B * g.npix, st));
+    HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
 
     STAGE("k_decimate_minmax");
     hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
     STAGE("k_threshold");
     hipLaunchKernelGGL(k_threshold, dim3((twx + 63) / 64, (g.sh + 3) / 4, B), blk, 0, st, d->dgray.p, g, d->tmin.p, d->tmax.p, d->thresh.p);
 
-    STAGE("k_cc_init");
+    STAGE("k_cc_tile");
     dim3 pgrid((g.sw + 63) / 64, (g.sh + 3) / 4, B);
-    hipLaunchKernelGGL(k_cc_init, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
-    STAGE("k_cc_merge");
-    hipLaunchKernelGGL(k_cc_merge, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p);
+    dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
+    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
+    STAGE("k_cc_border");
+    hipLaunchKernelGGL(k_cc_border, cgrid, dim3(128), 0, st, d->thresh.p, g, d->parent.p);
     STAGE("k_cc_flatten");
-    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
+    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, g, d->parent.p, d->sizes.p);
 
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_cluster_count");
     dim3 tgrid((g.sw + 15) / 16, (g.sh + 15) / 16, B);  // wave = 16x4 pixel tile
     hipLaunchKernelGGL(k_cluster_count, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p,
-                       d->nslots - 1, d->counters.p);
+                       d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");
-    hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots, g,
+    hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 1023) / 1024), dim3(1024), 0, st, d->hkeys.p, d->hcounts.p, d->nslots, g,
                        d->clusters.p, d->slot_cluster.p, d->class_lists.p, d->max_clusters, d->max_points, d->counters.p);
-    STAGE("k_cluster_scatter");
-    hipLaunchKernelGGL(k_cluster_scatter, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->nslots - 1,
+    STAGE("k_point_place");
+    hipLaunchKernelGGL(k_point_place, dim3(16, B), dim3(256), 0, st, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
                        d->slot_cluster.p, d->clusters.p, d->points.p);
 
     // one launch per size class; each walks its own cluster list (grid-stride)
@@ -434,19 +443,32 @@ static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hi
         for (int i = 0; i < d->nev; i++) HIPCHK(hipEventElapsedTime(&d->stage_ms[i], d->ev[i], d->ev[i + 1]));
     }
     size_t nd = (size_t)d->last_counters[CNT_NDETS];
-    d->host_dets.resize(nd);
-    if (nd) HIPCHK(hipMemcpy(d->host_dets.data(), d->dets.p, nd * sizeof(DetRec), hipMemcpyDeviceToHost));
-    std::sort(d->host_dets.begin(), d->host_dets.end(), det_key_less);
-    std::vector<DetRec> fin;
+    if (nd > d->host_dets_cap) {
+        if (d->host_dets) (void)hipHostFree(d->host_dets);
+        d->host_dets = nullptr;
+        d->host_dets_cap = 0;
+        size_t want = std::max<size_t>(nd * 2, 4096);
+        HIPCHK(hipHostMalloc((void **)&d->host_dets, want * sizeof(DetRec), hipHostMallocDefault));
+        d->host_dets_cap = want;
+    }
+    if (nd) HIPCHK(hipMemcpy(d->host_dets, d->dets.p, nd * sizeof(DetRec), hipMemcpyDeviceToHost));
+    // order by (frame, cluster key) = the oracle's visiting order; sort indices, not 330-byte records
+    std::vector<unsigned int> order(nd);
+    for (size_t k = 0; k < nd; k++) order[k] = (unsigned int)k;
+    const DetRec *hd = d->host_dets;
+    std::sort(order.begin(), order.end(), [hd](unsigned int a, unsigned int b) { return det_key_less(hd[a], hd[b]); });
+    std::vector<DetRec> fin, one;
     fin.reserve(nd);
     std::vector<int> counts((size_t)g.nframes, 0);
     size_t i = 0;
     while (i < nd) {
         size_t j = i;
-        while (j < nd && d->host_dets[j].frame == d->host_dets[i].frame) j++;
+        int fr = hd[order[i]].frame;
+        one.clear();
+        while (j < nd && hd[order[j]].frame == fr) one.push_back(hd[order[j++]]);
         size_t before = fin.size();
-        dedup_frame(d->host_dets, i, j, fin);
-        counts[(size_t)d->host_dets[i].frame] = (int)(fin.size() - before);
+        dedup_frame(one, 0, one.size(), fin);
+        if (fr >= 0 && fr < g.nframes) counts[(size_t)fr] = (int)(fin.size() - before);
         i = j;
     }
     int total = (int)fin.size();

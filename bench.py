@@ -51,12 +51,10 @@ def algorithmic_bytes(kernel, w, h, ch, f):
     table = {
         "k_decimate_minmax": full + npix + 2 * ntile,
         "k_threshold": npix + 2 * ntile + npix,
-        "k_cc_init": npix + 4 * npix,
-        "k_cc_merge": npix + 4 * npix,
-        "k_cc_flatten": npix + 4 * npix + 4 * npix + 4 * npix,
+        "k_cc_tile": npix + 4 * npix + 4 * npix,
+        "k_cc_flatten": 4 * npix + 4 * npix + 4 * npix,
         "k_cluster_count": npix + 4 * npix + 4 * npix,
-        "k_cluster_scatter": npix + 4 * npix + 4 * npix,
-        "memset": 4 * npix,
+        "k_cluster_count": npix + 4 * npix + 4 * npix,
     }
     return table.get(kernel)
 
@@ -169,8 +167,8 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
                     "algorithmic_bytes_per_frame": pts * 9}
-        seg = sum(avg.get(k, 0.0) for k in ("memset", "k_decimate_minmax", "k_threshold", "k_cc_init", "k_cc_merge", "k_cc_flatten",
-                                             "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_cluster_scatter"))
+        seg = sum(avg.get(k, 0.0) for k in ("memset", "k_decimate_minmax", "k_threshold", "k_cc_tile", "k_cc_border", "k_cc_flatten",
+                                             "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_point_place"))
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
         seg_gbs = seg_bytes * B / (seg * 1e-3) / 1e9 if seg > 0 else 0.0
         line = {
