@@ -285,7 +285,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_cluster_count");
-    dim3 tgrid((g.sw + 15) / 16, (g.sh + 15) / 16, B);  // wave = 16x4 pixel tile
+    dim3 tgrid(B, (g.sw + CNT_TW - 1) / CNT_TW, (g.sh + CNT_TH - 1) / CNT_TH);  // workgroup = 64x16 pixel tile, frame-major
     hipLaunchKernelGGL(k_cluster_count, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p,
                        d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;

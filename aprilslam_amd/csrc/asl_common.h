@@ -111,6 +111,14 @@ __device__ __forceinline__ int gray_at(const uint8_t *frame, const Geom &g, int 
 {
     const uint8_t *p = frame + (size_t)y * g.stride;
     if (g.channels == 1) return p[x];
-    int b = p[3 * x], gg = p[3 * x + 1], r = p[3 * x + 2];
+    int b, gg, r;
+    if (x + 1 < g.w) {
+        // one (possibly unaligned) 4-byte fetch instead of three byte loads; the 4th byte is the next pixel's B
+        unsigned int u;
+        __builtin_memcpy(&u, p + 3 * x, 4);
+        b = u & 0xFF; gg = (u >> 8) & 0xFF; r = (u >> 16) & 0xFF;
+    } else {
+        b = p[3 * x]; gg = p[3 * x + 1]; r = p[3 * x + 2];
+    }
     return (b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15;  // cv2 BGR2GRAY fixed point
 }
