@@ -140,13 +140,25 @@ class Detector:
 
     # -- frames resident in HBM ---------------------------------------------------------
     def detect_device(self, data_ptr, n_frames, channels, width, height, stride=None, frame_pitch=None, stream=0,
-                      K=None, dist=None, tag_size=0.0, max_per_frame=64, want_poses=None):
+                      K=None, dist=None, tag_size=0.0, max_per_frame=64, want_poses=None, reuse_buffers=False):
         stride = stride or width * channels
         frame_pitch = frame_pitch or stride * height
         cap = n_frames * max_per_frame
-        out = np.empty(cap, dtype=DET_DTYPE)
         want_poses = (K is not None) if want_poses is None else want_poses
-        poses = np.empty(cap if want_poses else 0, dtype=POSE_DTYPE)
+        # result buffers are kept and reused (fresh multi-MB arrays cost ~1 ms of page faults per call);
+        # the returned arrays are views into them, valid until the next call on this detector
+        if reuse_buffers and getattr(self, "_outbuf", None) is not None and len(self._outbuf) >= cap:
+            out = self._outbuf
+        else:
+            out = np.empty(cap, dtype=DET_DTYPE)
+            self._outbuf = out if reuse_buffers else None
+        if not want_poses:
+            poses = np.empty(0, dtype=POSE_DTYPE)
+        elif reuse_buffers and getattr(self, "_posebuf", None) is not None and len(self._posebuf) >= cap:
+            poses = self._posebuf
+        else:
+            poses = np.empty(cap, dtype=POSE_DTYPE)
+            self._posebuf = poses if reuse_buffers else None
         npf = (C.c_int * n_frames)()
         n = C.c_int()
         dp = C.POINTER(C.c_double)
@@ -166,7 +178,8 @@ class Detector:
                                               C.byref(n)))
         if n.value > cap:
             return self.detect_device(data_ptr, n_frames, channels, width, height, stride, frame_pitch, stream, K, dist,
-                                      tag_size, max_per_frame=(n.value + n_frames - 1) // n_frames + 1, want_poses=want_poses)
+                                      tag_size, max_per_frame=(n.value + n_frames - 1) // n_frames + 1, want_poses=want_poses,
+                                      reuse_buffers=reuse_buffers)
         return out[:n.value], (poses[:n.value] if want_poses else None), np.array(list(npf), dtype=np.int64)
 
     def solve_pnp(self, corners, K, dist, tag_size):
@@ -183,6 +196,23 @@ class Detector:
                                           rvec.ctypes.data_as(dp), tvec.ctypes.data_as(dp), T.ctypes.data_as(dp),
                                           ok.ctypes.data_as(C.POINTER(C.c_uint8)), N))
         return rvec, tvec, T, ok.astype(bool)
+
+    def gn_solve(self, cam_T, tag_T, obs_cam, obs_tag, obs_corners, K, tag_size, fixed_tag=0, iters=10):
+        """Pose-graph Levenberg-Marquardt on the device (asl_gn_solve).  cam_T (P,4,4) world<-camera,
+        tag_T (L,4,4) world<-tag, observations (cam index, tag index, 4x2 pixel corners).
+        Returns refined (cam_T, tag_T, stats=[cost0, cost, accepted])."""
+        cam = np.ascontiguousarray(cam_T, dtype=np.float64).reshape(-1, 16).copy()
+        tag = np.ascontiguousarray(tag_T, dtype=np.float64).reshape(-1, 16).copy()
+        oc = np.ascontiguousarray(obs_cam, dtype=np.int32)
+        ot = np.ascontiguousarray(obs_tag, dtype=np.int32)
+        corners = np.ascontiguousarray(obs_corners, dtype=np.float64).reshape(-1, 8)
+        Kc = np.ascontiguousarray(K, dtype=np.float64)
+        stats = np.zeros(3)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        check(self._L.asl_gn_solve(self._h, cam.shape[0], tag.shape[0], len(oc), oc.ctypes.data_as(ip), ot.ctypes.data_as(ip),
+                                   corners.ctypes.data_as(dp), Kc.ctypes.data_as(dp), float(tag_size), int(fixed_tag),
+                                   cam.ctypes.data_as(dp), tag.ctypes.data_as(dp), int(iters), stats.ctypes.data_as(dp)))
+        return cam.reshape(-1, 4, 4), tag.reshape(-1, 4, 4), stats
 
     # -- introspection for the parity tests ------------------------------------------------
     def debug_counters(self):

@@ -4,6 +4,7 @@
 #include "../../include/aprilslam.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -40,22 +41,6 @@ static int fail(int code, const char *fmt, ...)
         hipError_t e__ = (expr);                                                                       \
         if (e__ != hipSuccess) return fail(ASL_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
-
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int ensure(size_t want)
-    {
-        if (want <= n) return 0;
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return -1; }
-        n = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
 
 #define MAX_STAGES 24
 
@@ -95,6 +80,7 @@ struct asl_detector {
     Geom last{};
     unsigned int nslots = 0, max_clusters = 0, max_points = 0, max_dets = 0;
     long long last_counters[CNT__N] = {0};
+    long long *pinned_counters = nullptr;  // D2H target that does not force a blocking staging copy
     DetRec *host_dets = nullptr;  // pinned
     size_t host_dets_cap = 0;
 
@@ -105,6 +91,7 @@ struct asl_detector {
     const char *stage_names[MAX_STAGES] = {nullptr};
     float stage_ms[MAX_STAGES] = {0};
     int nstages = 0;
+    float host_ms[4] = {0, 0, 0, 0};  // enqueue, wait, copy, post-process of the last batch
 };
 
 static const char *kVersion = "aprilslam 0.1 gfx950 (HIP, tagStandard41h12)";
@@ -168,6 +155,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     d->gn.release();
     if (d->d_codes) (void)hipFree(d->d_codes);
     if (d->host_dets) (void)hipHostFree(d->host_dets);
+    if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
     for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
     delete d;
 }
@@ -187,6 +175,8 @@ extern "C" int asl_stage_times(asl_detector *d, const char **names, float *ms, i
     if (!d || !n) return fail(ASL_EINVAL, "NULL argument");
     int k = std::min(max_n, d->nstages);
     for (int i = 0; i < k; i++) { if (names) names[i] = d->stage_names[i]; if (ms) ms[i] = d->stage_ms[i]; }
+    static const char *hn[4] = {"host_enqueue", "host_wait", "host_copy", "host_post"};
+    for (int i = 0; i < 4 && k < max_n; i++, k++) { if (names) names[k] = hn[i]; if (ms) ms[k] = d->host_ms[i]; }
     *n = k;
     return ASL_OK;
 }
@@ -390,40 +380,49 @@ static bool det_key_less(const DetRec &a, const DetRec &b)
     return a.key < b.key;
 }
 
-// dedup within [lo, hi) (one frame, already in cluster-key order = the oracle's visiting order)
-static void dedup_frame(std::vector<DetRec> &v, size_t lo, size_t hi, std::vector<DetRec> &out)
+// dedup one frame given as indices into hd (already in cluster-key order = the oracle's visiting
+// order); survivors are appended to `out` sorted by (id, hamming, corners)
+static void dedup_frame(const DetRec *hd, std::vector<unsigned int> &idx, std::vector<unsigned int> &out)
 {
-    std::vector<DetRec> d(v.begin() + lo, v.begin() + hi);
-    int n = (int)d.size();
+    int n = (int)idx.size();
     for (int i0 = 0; i0 < n; i0++) {
         for (int i1 = i0 + 1; i1 < n; i1++) {
-            if (d[i0].id != d[i1].id) continue;
-            if (!quads_overlap(d[i0].corners, d[i1].corners)) continue;
+            const DetRec &a = hd[idx[i0]], &b = hd[idx[i1]];
+            if (a.id != b.id) continue;
+            if (!quads_overlap(a.corners, b.corners)) continue;
             int pref = 0;
-            pref = prefer_smaller(pref, d[i0].hamming, d[i1].hamming);
-            pref = prefer_smaller(pref, -d[i0].margin, -d[i1].margin);
+            pref = prefer_smaller(pref, a.hamming, b.hamming);
+            pref = prefer_smaller(pref, -a.margin, -b.margin);
             for (int i = 0; i < 4; i++) {
-                pref = prefer_smaller(pref, d[i0].corners[i][0], d[i1].corners[i][0]);
-                pref = prefer_smaller(pref, d[i0].corners[i][1], d[i1].corners[i][1]);
+                pref = prefer_smaller(pref, a.corners[i][0], b.corners[i][0]);
+                pref = prefer_smaller(pref, a.corners[i][1], b.corners[i][1]);
             }
-            if (pref < 0) { d.erase(d.begin() + i1); n--; i1--; }
-            else { d.erase(d.begin() + i0); n--; i0--; break; }
+            if (pref < 0) { idx.erase(idx.begin() + i1); n--; i1--; }
+            else { idx.erase(idx.begin() + i0); n--; i0--; break; }
         }
     }
-    std::sort(d.begin(), d.end(), det_less);
-    out.insert(out.end(), d.begin(), d.end());
+    std::sort(idx.begin(), idx.end(), [hd](unsigned int a, unsigned int b) { return det_less(hd[a], hd[b]); });
+    out.insert(out.end(), idx.begin(), idx.end());
 }
 
 static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam,
                      asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
 {
+    using clk = std::chrono::steady_clock;
+    auto msf = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
+    clk::time_point t0 = clk::now(), t1 = t0, t2 = t0;
     for (int attempt = 0; attempt < 4; attempt++) {
         int rc = ensure_workspace(d, g);
         if (rc) return rc;
+        t0 = clk::now();
         rc = enqueue_detect(d, d_frames, g, st, cam);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(d->last_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
+        if (!d->pinned_counters) HIPCHK(hipHostMalloc((void **)&d->pinned_counters, sizeof(long long) * CNT__N, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(d->pinned_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
+        t1 = clk::now();
         HIPCHK(hipStreamSynchronize(st));
+        t2 = clk::now();
+        memcpy(d->last_counters, d->pinned_counters, sizeof(long long) * CNT__N);
         d->last = g;
         long long *c = d->last_counters;
         bool again = false;
@@ -452,12 +451,16 @@ static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hi
         d->host_dets_cap = want;
     }
     if (nd) HIPCHK(hipMemcpy(d->host_dets, d->dets.p, nd * sizeof(DetRec), hipMemcpyDeviceToHost));
+    clk::time_point t3 = clk::now();
     // order by (frame, cluster key) = the oracle's visiting order; sort indices, not 330-byte records
-    std::vector<unsigned int> order(nd);
-    for (size_t k = 0; k < nd; k++) order[k] = (unsigned int)k;
     const DetRec *hd = d->host_dets;
-    std::sort(order.begin(), order.end(), [hd](unsigned int a, unsigned int b) { return det_key_less(hd[a], hd[b]); });
-    std::vector<DetRec> fin, one;
+    // the cluster key carries the frame in its top 16 bits, so sorting (key, index) pairs orders by (frame, cluster)
+    std::vector<std::pair<unsigned long long, unsigned int>> keyed(nd);
+    for (size_t k = 0; k < nd; k++) keyed[k] = std::make_pair((unsigned long long)hd[k].key, (unsigned int)k);
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<unsigned int> order(nd);
+    for (size_t k = 0; k < nd; k++) order[k] = keyed[k].second;
+    std::vector<unsigned int> fin, one;
     fin.reserve(nd);
     std::vector<int> counts((size_t)g.nframes, 0);
     size_t i = 0;
@@ -465,31 +468,33 @@ static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hi
         size_t j = i;
         int fr = hd[order[i]].frame;
         one.clear();
-        while (j < nd && hd[order[j]].frame == fr) one.push_back(hd[order[j++]]);
+        while (j < nd && hd[order[j]].frame == fr) one.push_back(order[j++]);
         size_t before = fin.size();
-        dedup_frame(one, 0, one.size(), fin);
+        dedup_frame(hd, one, fin);
         if (fr >= 0 && fr < g.nframes) counts[(size_t)fr] = (int)(fin.size() - before);
         i = j;
     }
     int total = (int)fin.size();
     int nw = std::min(total, max_out);
     for (int k = 0; k < nw; k++) {
-        const DetRec &r = fin[(size_t)k];
+        const DetRec &r = hd[fin[(size_t)k]];
         if (out) {
             asl_detection &o = out[k];
             o.id = r.id; o.hamming = r.hamming; o.margin = r.margin; o.frame = r.frame;
-            o.center[0] = r.center[0]; o.center[1] = r.center[1];
-            for (int a = 0; a < 4; a++) { o.corners[a][0] = r.corners[a][0]; o.corners[a][1] = r.corners[a][1]; }
+            memcpy(o.center, r.center, sizeof o.center);
+            memcpy(o.corners, r.corners, sizeof o.corners);
         }
         if (poses && cam) {
             asl_pose &p = poses[k];
-            for (int a = 0; a < 3; a++) { p.rvec[a] = r.rvec[a]; p.tvec[a] = r.tvec[a]; }
-            for (int a = 0; a < 16; a++) p.T[a] = r.T[a];
+            memcpy(p.rvec, r.rvec, sizeof p.rvec);
+            memcpy(p.tvec, r.tvec, sizeof p.tvec);
+            memcpy(p.T, r.T, sizeof p.T);
             p.ok = r.pose_ok; p.reserved = 0;
         }
     }
     if (n_per_frame) for (int f = 0; f < g.nframes; f++) n_per_frame[f] = counts[(size_t)f];
     if (n_out) *n_out = total;
+    d->host_ms[0] = msf(t0, t1); d->host_ms[1] = msf(t1, t2); d->host_ms[2] = msf(t2, t3); d->host_ms[3] = msf(t3, clk::now());
     return ASL_OK;
 }
 

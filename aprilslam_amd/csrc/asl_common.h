@@ -18,6 +18,23 @@
 #define CLASS1_CAP 256
 #define CLASS2_CAP 1024
 
+// growable device buffer
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t want)
+    {
+        if (want <= n) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return -1; }
+        n = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
 // Geometry of one batch, passed by value to every kernel.
 struct Geom {
     int w, h;          // full-resolution frame

@@ -132,7 +132,7 @@ def main():
         torch.cuda.set_device(local_rank)
         sub = d_frames[starts[i]:starts[i] + part[i]]
         return detectors[i].detect_device(sub.data_ptr(), part[i], 3, W, H, stream=streams[i].cuda_stream, K=K, dist=zeros4,
-                                          tag_size=TAG_INNER)
+                                          tag_size=TAG_INNER, reuse_buffers=True)
 
     def step():
         res = list(pool.map(run_part, range(P)))

@@ -128,3 +128,20 @@ def test_errors_are_loud(gpu_detector):
         _lib.Detector("tagStandard41h12", decimate=1.5)
     with pytest.raises(_lib.AslError):
         _lib.Detector("tagStandard41h12", blur=0.8)
+
+
+def test_gn_backend_matches_cpu_restatement(gpu_detector):
+    """Pose-graph LM on the device (MFMA f64 normal blocks) vs oracle/gn_oracle.py: same damping schedule,
+    so the iterates agree to rounding; and both recover ground truth on noise-free data."""
+    from gn_problem import G, make_problem
+    for seed, noise in ((3, 0.0), (4, 0.25)):
+        pr = make_problem(P=16, L=8, seed=seed, noise=noise)
+        args = (pr["cam0"], pr["tag0"], pr["obs_cam"], pr["obs_tag"], pr["obs_corners"], pr["K"], 10.0, 0)
+        cam_o, tag_o, st_o = G.solve(*args, iters=12)
+        cam_g, tag_g, st_g = gpu_detector.gn_solve(*args, iters=12)
+        assert abs(st_g[2] - st_o[2]) <= 2  # at convergence the accept test is decided by rounding
+        assert abs(st_g[0] - st_o[0]) <= 1e-9 * st_o[0]
+        assert abs(st_g[1] - st_o[1]) <= 1e-6 * max(st_o[1], 1e-9) + 1e-12 * st_o[0]
+        assert np.abs(tag_g - tag_o).max() < 1e-6 and np.abs(cam_g - cam_o).max() < 1e-6
+        if noise == 0.0:
+            assert np.abs(tag_g - pr["tag_gt"]).max() < 1e-6 and np.abs(cam_g - pr["cam_gt"]).max() < 1e-6
