@@ -37,7 +37,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_device", "asl_solve_pnp_batch", "asl_gn_solve",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -71,6 +71,8 @@ def load():
     L.asl_detect_batch_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.asl_detect_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double,
                                           vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.asl_submit_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double]
+    L.asl_collect_batch.argtypes = [vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.asl_solve_pnp_batch.argtypes = [vp, C.POINTER(C.c_float), dp, dp, i32, C.c_double, dp, dp, dp, u8p, i32]
     L.asl_gn_solve.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_double, i32,
                                dp, dp, i32, dp]
@@ -181,6 +183,41 @@ class Detector:
                                       tag_size, max_per_frame=(n.value + n_frames - 1) // n_frames + 1, want_poses=want_poses,
                                       reuse_buffers=reuse_buffers)
         return out[:n.value], (poses[:n.value] if want_poses else None), np.array(list(npf), dtype=np.int64)
+
+    def submit_device(self, data_ptr, n_frames, channels, width, height, stride=None, frame_pitch=None, stream=0, K=None,
+                      dist=None, tag_size=0.0):
+        """Enqueue a batch resident in HBM and return immediately (asl_submit_batch_device); pair with collect()."""
+        stride = stride or width * channels
+        frame_pitch = frame_pitch or stride * height
+        dp = C.POINTER(C.c_double)
+        if K is not None:
+            Kc = np.ascontiguousarray(K, dtype=np.float64)
+            dc = np.ascontiguousarray(np.zeros(0) if dist is None else dist, dtype=np.float64).ravel()
+            if len(dc) not in (0, 4, 5):
+                raise ValueError("dist must have 0, 4 or 5 coefficients")
+            Kp, dpp, nd = Kc.ctypes.data_as(dp), (dc.ctypes.data_as(dp) if len(dc) else None), len(dc)
+        else:
+            Kp, dpp, nd = None, None, 0
+        check(self._L.asl_submit_batch_device(self._h, C.c_void_p(int(data_ptr)), n_frames, channels, width, height, stride,
+                                              frame_pitch, C.c_void_p(int(stream)), Kp, dpp, nd, float(tag_size)))
+        self._inflight = (n_frames, K is not None)
+
+    def collect(self, max_per_frame=64):
+        """Wait for the submitted batch; returns (dets, poses or None, n_per_frame).  The arrays are views into
+        buffers owned by the detector, valid until its next collect()."""
+        n_frames, want_poses = self._inflight
+        cap = n_frames * max_per_frame
+        if getattr(self, "_outbuf", None) is None or len(self._outbuf) < cap:
+            self._outbuf = np.empty(cap, dtype=DET_DTYPE)
+        if want_poses and (getattr(self, "_posebuf", None) is None or len(self._posebuf) < cap):
+            self._posebuf = np.empty(cap, dtype=POSE_DTYPE)
+        npf = (C.c_int * n_frames)()
+        n = C.c_int()
+        check(self._L.asl_collect_batch(self._h, self._outbuf.ctypes.data, self._posebuf.ctypes.data if want_poses else None,
+                                        cap, npf, C.byref(n)))
+        if n.value > cap:
+            raise AslError("more than %d detections per frame on average; raise max_per_frame" % max_per_frame)
+        return self._outbuf[:n.value], (self._posebuf[:n.value] if want_poses else None), np.frombuffer(npf, dtype=np.int32)
 
     def solve_pnp(self, corners, K, dist, tag_size):
         c = np.ascontiguousarray(np.asarray(corners, dtype=np.float32).reshape(-1, 4, 2))

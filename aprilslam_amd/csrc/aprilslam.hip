@@ -80,6 +80,15 @@ struct asl_detector {
     Geom last{};
     unsigned int nslots = 0, max_clusters = 0, max_points = 0, max_dets = 0;
     long long last_counters[CNT__N] = {0};
+    // batch in flight (asl_submit_batch_device .. asl_collect_batch)
+    bool pending = false;
+    const uint8_t *p_frames = nullptr;
+    Geom p_geom{};
+    hipStream_t p_stream = nullptr;
+    bool p_has_cam = false;
+    CamDev p_cam{};
+    size_t prefetched = 0, nd_guess = 0;
+    std::chrono::steady_clock::time_point t_submit, t_enqueued;
     long long *pinned_counters = nullptr;  // D2H target that does not force a blocking staging copy
     DetRec *host_dets = nullptr;  // pinned
     size_t host_dets_cap = 0;
@@ -405,21 +414,62 @@ static void dedup_frame(const DetRec *hd, std::vector<unsigned int> &idx, std::v
     out.insert(out.end(), idx.begin(), idx.end());
 }
 
-static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam,
-                     asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+using clk = std::chrono::steady_clock;
+static float msf(clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); }
+
+static int ensure_host_dets(asl_detector *d, size_t want)
 {
-    using clk = std::chrono::steady_clock;
-    auto msf = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
-    clk::time_point t0 = clk::now(), t1 = t0, t2 = t0;
+    if (want <= d->host_dets_cap) return ASL_OK;
+    if (d->host_dets) (void)hipHostFree(d->host_dets);
+    d->host_dets = nullptr;
+    d->host_dets_cap = 0;
+    want = std::max<size_t>(want * 2, 4096);
+    HIPCHK(hipHostMalloc((void **)&d->host_dets, want * sizeof(DetRec), hipHostMallocNonCoherent));  // coarse-grained: CPU-cached
+    d->host_dets_cap = want;
+    return ASL_OK;
+}
+
+// enqueue one batch and the asynchronous read-back of its counters (and of as many detection records as the
+// previous batch produced, so that the usual case needs no second copy); returns without waiting
+static int submit_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
+{
+    if (d->pending) return fail(ASL_EINVAL, "a batch is already in flight on this detector: collect it first");
+    int rc = ensure_workspace(d, g);
+    if (rc) return rc;
+    d->t_submit = clk::now();
+    rc = enqueue_detect(d, d_frames, g, st, cam);
+    if (rc) return rc;
+    if (!d->pinned_counters) HIPCHK(hipHostMalloc((void **)&d->pinned_counters, sizeof(long long) * CNT__N, hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(d->pinned_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
+    d->prefetched = 0;
+    if (d->nd_guess > 0) {
+        size_t guess = std::min<size_t>(d->nd_guess, d->max_dets);
+        rc = ensure_host_dets(d, guess);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d->host_dets, d->dets.p, guess * sizeof(DetRec), hipMemcpyDeviceToHost, st));
+        d->prefetched = guess;
+    }
+    d->pending = true;
+    d->p_frames = d_frames; d->p_geom = g; d->p_stream = st; d->p_has_cam = cam != nullptr;
+    if (cam) d->p_cam = *cam;
+    d->t_enqueued = clk::now();
+    return ASL_OK;
+}
+
+static int collect_batch(asl_detector *d, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+{
+    if (!d->pending) return fail(ASL_EINVAL, "no batch in flight on this detector");
+    const Geom g = d->p_geom;
+    hipStream_t st = d->p_stream;
+    const CamDev *cam = d->p_has_cam ? &d->p_cam : nullptr;
+    clk::time_point t0 = d->t_submit, t1 = d->t_enqueued, t2 = t1;
     for (int attempt = 0; attempt < 4; attempt++) {
-        int rc = ensure_workspace(d, g);
-        if (rc) return rc;
-        t0 = clk::now();
-        rc = enqueue_detect(d, d_frames, g, st, cam);
-        if (rc) return rc;
-        if (!d->pinned_counters) HIPCHK(hipHostMalloc((void **)&d->pinned_counters, sizeof(long long) * CNT__N, hipHostMallocDefault));
-        HIPCHK(hipMemcpyAsync(d->pinned_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
-        t1 = clk::now();
+        if (attempt > 0) {  // a work buffer overflowed: grow it and run the batch again, synchronously
+            d->pending = false;
+            d->nd_guess = 0;
+            int rc = submit_batch(d, d->p_frames, g, st, cam);
+            if (rc) return rc;
+        }
         HIPCHK(hipStreamSynchronize(st));
         t2 = clk::now();
         memcpy(d->last_counters, d->pinned_counters, sizeof(long long) * CNT__N);
@@ -431,26 +481,29 @@ static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hi
         if (c[CNT_OVERFLOW_POINTS]) { d->points_per_pixel *= 2; again = true; }
         if (c[CNT_OVERFLOW_DETS]) { d->dets_per_frame *= 4; again = true; }
         if (again) {
-            if (attempt == 3) return fail(ASL_ECAPACITY, "work buffers still overflow after growing (hash %lld clusters %lld points %lld dets %lld)",
-                                          c[CNT_OVERFLOW_HASH], c[CNT_OVERFLOW_CLUSTERS], c[CNT_OVERFLOW_POINTS], c[CNT_OVERFLOW_DETS]);
+            if (attempt == 3) {
+                d->pending = false;
+                return fail(ASL_ECAPACITY, "work buffers still overflow after growing (hash %lld clusters %lld points %lld dets %lld)",
+                            c[CNT_OVERFLOW_HASH], c[CNT_OVERFLOW_CLUSTERS], c[CNT_OVERFLOW_POINTS], c[CNT_OVERFLOW_DETS]);
+            }
             continue;
         }
         break;
     }
+    d->pending = false;
     if (d->profiling) {
         d->nstages = d->nev;
         for (int i = 0; i < d->nev; i++) HIPCHK(hipEventElapsedTime(&d->stage_ms[i], d->ev[i], d->ev[i + 1]));
     }
     size_t nd = (size_t)d->last_counters[CNT_NDETS];
-    if (nd > d->host_dets_cap) {
-        if (d->host_dets) (void)hipHostFree(d->host_dets);
-        d->host_dets = nullptr;
-        d->host_dets_cap = 0;
-        size_t want = std::max<size_t>(nd * 2, 4096);
-        HIPCHK(hipHostMalloc((void **)&d->host_dets, want * sizeof(DetRec), hipHostMallocDefault));
-        d->host_dets_cap = want;
+    if (nd > d->prefetched) {
+        size_t have = d->prefetched;
+        if (nd > d->host_dets_cap) have = 0;  // the staging buffer is about to be replaced
+        int rc = ensure_host_dets(d, nd);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(d->host_dets + have, d->dets.p + have, (nd - have) * sizeof(DetRec), hipMemcpyDeviceToHost));
     }
-    if (nd) HIPCHK(hipMemcpy(d->host_dets, d->dets.p, nd * sizeof(DetRec), hipMemcpyDeviceToHost));
+    d->nd_guess = nd + nd / 4 + 256;
     clk::time_point t3 = clk::now();
     // order by (frame, cluster key) = the oracle's visiting order; sort indices, not 330-byte records
     const DetRec *hd = d->host_dets;
@@ -498,21 +551,45 @@ static int run_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g, hi
     return ASL_OK;
 }
 
+static int check_device_args(asl_detector *d, const void *d_frames, int n_frames, int channels, int w, int h, int stride, size_t frame_pitch,
+                             int n_dist, Geom *g)
+{
+    if (!d || !d_frames) return fail(ASL_EINVAL, "NULL detector or frames");
+    if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
+    HIPCHK(hipSetDevice(d->device));
+    int rc = make_geom(d, n_frames, channels, w, h, stride, frame_pitch, g);
+    if (rc) return rc;
+    if (frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "frame_pitch smaller than one frame");
+    return ASL_OK;
+}
+
+extern "C" int asl_submit_batch_device(asl_detector *d, const void *d_frames, int n_frames, int channels, int w, int h, int stride,
+                                       size_t frame_pitch, void *stream, const double *K, const double *dist, int n_dist, double tag_size)
+{
+    Geom g;
+    int rc = check_device_args(d, d_frames, n_frames, channels, w, h, stride, frame_pitch, n_dist, &g);
+    if (rc) return rc;
+    CamDev cam;
+    if (K) cam = make_cam(K, dist, n_dist, tag_size);
+    return submit_batch(d, (const uint8_t *)d_frames, g, (hipStream_t)stream, K ? &cam : nullptr);
+}
+
+extern "C" int asl_collect_batch(asl_detector *d, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+{
+    if (!d) return fail(ASL_EINVAL, "NULL detector");
+    if (max_out < 0 || (max_out > 0 && !out)) return fail(ASL_EINVAL, "out is NULL");
+    HIPCHK(hipSetDevice(d->device));
+    return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
+}
+
 extern "C" int asl_detect_batch_device(asl_detector *d, const void *d_frames, int n_frames, int channels, int w, int h, int stride,
                                        size_t frame_pitch, void *stream, const double *K, const double *dist, int n_dist,
                                        double tag_size, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
 {
-    if (!d || !d_frames) return fail(ASL_EINVAL, "NULL detector or frames");
     if (max_out < 0 || (max_out > 0 && !out)) return fail(ASL_EINVAL, "out is NULL");
-    if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
-    HIPCHK(hipSetDevice(d->device));
-    Geom g;
-    int rc = make_geom(d, n_frames, channels, w, h, stride, frame_pitch, &g);
+    int rc = asl_submit_batch_device(d, d_frames, n_frames, channels, w, h, stride, frame_pitch, stream, K, dist, n_dist, tag_size);
     if (rc) return rc;
-    if (frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "frame_pitch smaller than one frame");
-    CamDev cam;
-    if (K) cam = make_cam(K, dist, n_dist, tag_size);
-    return run_batch(d, (const uint8_t *)d_frames, g, (hipStream_t)stream, K ? &cam : nullptr, out, poses, max_out, n_per_frame, n_out);
+    return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
 }
 
 extern "C" int asl_detect_batch_u8(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
@@ -529,7 +606,9 @@ extern "C" int asl_detect_batch_u8(asl_detector *d, const uint8_t *const *frames
         if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
         HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
     }
-    return run_batch(d, d->in.p, g, nullptr, nullptr, out, nullptr, max_out, n_per_frame, n_out);
+    int rcs = submit_batch(d, d->in.p, g, nullptr, nullptr);
+    if (rcs) return rcs;
+    return collect_batch(d, out, nullptr, max_out, n_per_frame, n_out);
 }
 
 extern "C" int asl_detect_gray_u8(asl_detector *d, const uint8_t *gray, int w, int h, int stride, asl_detection *out, int max_out, int *n_out)

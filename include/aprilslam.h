@@ -98,6 +98,16 @@ int asl_detect_batch_device(asl_detector *det, const void *d_frames, int n_frame
                             double tag_size, asl_detection *out, asl_pose *poses, int max_out,
                             int *n_per_frame, int *n_out);
 
+/* The same call split in two so that batches can be pipelined: submit enqueues the whole batch (kernels and
+   the asynchronous read-back) on `stream` and returns immediately; collect waits for it, de-duplicates and
+   writes the results.  One batch may be in flight per detector; use two detectors (two workspaces) and
+   alternate them to keep the GPU busy while the host post-processes the previous batch. */
+int asl_submit_batch_device(asl_detector *det, const void *d_frames, int n_frames, int channels, int w, int h,
+                            int stride, size_t frame_pitch, void *stream, const double *K, const double *dist,
+                            int n_dist, double tag_size);
+int asl_collect_batch(asl_detector *det, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame,
+                      int *n_out);
+
 /* Replaces cv2.solvePnP(ITERATIVE) + cv2.Rodrigues for N tags at once (reference
    tag_detector.py:30-52).  corners: N x 4 x 2 float32 (lb,rb,rt,lt), K row-major 3x3,
    dist: n_dist in {0,4,5} coefficients (k1,k2,p1,p2[,k3]).  All pointers are host memory. */
