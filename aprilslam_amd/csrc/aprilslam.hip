@@ -54,7 +54,7 @@ struct asl_detector {
 
     // capacities (grow on overflow)
     unsigned int hash_slots_per_frame = 1024;
-    unsigned int clusters_per_frame = 1024;
+    unsigned int clusters_per_frame = 2048;
     unsigned int dets_per_frame = 256;
     double points_per_pixel = 0.5;
 
@@ -294,7 +294,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->clusters.p, d->slot_cluster.p, d->class_lists.p, d->max_clusters, d->max_points, d->counters.p);
     STAGE("k_point_place");
     hipLaunchKernelGGL(k_point_place, dim3(16, B), dim3(256), 0, st, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
-                       d->slot_cluster.p, d->clusters.p, d->points.p);
+                       d->slot_cluster.p, d->clusters.p, d->points.p, d->counters.p);
 
     // one launch per size class; each walks its own cluster list (grid-stride)
     const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;

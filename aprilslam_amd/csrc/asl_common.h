@@ -106,6 +106,13 @@ enum {
     CNT__N = 16
 };
 
+// A batch whose work buffers overflowed is re-run by the host after growing them; until then its cluster
+// lists and quad records have holes, so every consumer kernel backs out first thing.
+__device__ __forceinline__ bool batch_poisoned(const long long *counters)
+{
+    return (counters[CNT_OVERFLOW_HASH] | counters[CNT_OVERFLOW_POINTS] | counters[CNT_OVERFLOW_CLUSTERS] | counters[CNT_OVERFLOW_DETS]) != 0;
+}
+
 // Diagnostic build only (-DASL_PHASE_TIMING): per-phase shader-clock sums, one stamp per block.
 // The shipped library compiles these to nothing.
 __device__ unsigned long long g_phase_cycles[64];

@@ -145,3 +145,62 @@ def test_gn_backend_matches_cpu_restatement(gpu_detector):
         assert np.abs(tag_g - tag_o).max() < 1e-6 and np.abs(cam_g - cam_o).max() < 1e-6
         if noise == 0.0:
             assert np.abs(tag_g - pr["tag_gt"]).max() < 1e-6 and np.abs(cam_g - pr["cam_gt"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("w,h,ntags,seed", [(1920, 1080, 50, 21), (3840, 2160, 200, 22)])
+def test_large_config_stage_parity(gpu_detector, family, w, h, ntags, seed):
+    """BASELINE.json configs[2] (1080p, 50 tags) and configs[4] (2160p, 200 tags) as single-frame parity cases:
+    every stage bit-exact against the oracle, every tag found with its id."""
+    frame, _ = scene_frame(w, h, ntags, seed)
+    dets, npf = check_stages(gpu_detector, frame[None], family)
+    assert sorted(int(d["id"]) for d in dets) == list(range(ntags))
+
+
+def test_decimate_1_and_maxhamming_variants(family):
+    """Non-default detector options (the wrapper's keywords) stay in parity with the oracle."""
+    from aprilslam_amd import _lib
+    frame, _ = scene_frame(640, 480, 6, 31, noise=2.0)
+    for dec, mh, refine in ((1, 1, True), (2, 0, True), (2, 2, False), (3, 1, True)):
+        det = _lib.Detector("tagStandard41h12", decimate=float(dec), maxhamming=mh, refine_edges=refine)
+        try:
+            dets, _ = det.detect_host(frame)
+            gray = O.bgr2gray(frame)
+            ref = O.detect_gray(gray, family, dec, mh, 1 if refine else 0)
+            assert [int(d["id"]) for d in dets] == [r["id"] for r in ref], (dec, mh, refine)
+            for d, r in zip(dets, ref):
+                assert int(d["hamming"]) == r["hamming"]
+                assert np.abs(d["corners"] - r["corners"]).max() <= CORNER_TOL
+        finally:
+            det.close()
+
+
+def test_submit_collect_pipeline_equals_blocking_call(family):
+    """Two workspaces used round-robin (submit batch i before collecting batch i-1) give the same results as
+    the blocking call, batch by batch."""
+    import torch
+    from aprilslam_amd import _lib
+    K = synth.camera_matrix(640, 360)
+    batches = [np.stack([scene_frame(640, 360, 5, 300 + 10 * b + i)[0] for i in range(4)]) for b in range(3)]
+    dev = [torch.from_numpy(b).to("cuda:0") for b in batches]
+    a, b2 = _lib.Detector(), _lib.Detector()
+    try:
+        ref = [a.detect_device(t.data_ptr(), 4, 3, 640, 360, K=K, dist=np.zeros(4), tag_size=10.0) for t in dev]
+        ref = [(r[0].copy(), r[1].copy(), r[2].copy()) for r in ref]
+        dets = [a, b2]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got, inflight = [], []
+        for i, t in enumerate(dev):
+            k = i % 2
+            if len(inflight) == 2:
+                r = dets[inflight.pop(0)].collect()
+                got.append((r[0].copy(), r[1].copy(), r[2].copy()))
+            dets[k].submit_device(t.data_ptr(), 4, 3, 640, 360, stream=streams[k].cuda_stream, K=K, dist=np.zeros(4), tag_size=10.0)
+            inflight.append(k)
+        while inflight:
+            r = dets[inflight.pop(0)].collect()
+            got.append((r[0].copy(), r[1].copy(), r[2].copy()))
+        for (d0, p0, n0), (d1, p1, n1) in zip(ref, got):
+            assert np.array_equal(n0, n1) and np.array_equal(d0["id"], d1["id"]) and np.array_equal(d0["corners"], d1["corners"])
+            assert np.array_equal(p0["tvec"], p1["tvec"]) and np.array_equal(p0["rvec"], p1["rvec"])
+    finally:
+        a.close(); b2.close()
