@@ -148,7 +148,7 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
     }
     d->fam.codes = d->d_codes;
     // class-2 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS2_CAP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS2_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS2_CAP);
     *out = d;
     return ASL_OK;
 }
@@ -300,18 +300,18 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
     unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 16384u);
     STAGE("k_fit_quads<0>");
-    hipLaunchKernelGGL((k_fit_quads<64, true>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
+    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<1>");
-    hipLaunchKernelGGL((k_fit_quads<64, true>), dim3(qgrid), dim3(64), 64 * CLASS1_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS1_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS1_CAP, st, d->clusters.p,
                        d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<2>");
-    hipLaunchKernelGGL((k_fit_quads<256, true>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
                        d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<3>");
-    hipLaunchKernelGGL((k_fit_quads<256, false>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
                        d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, 0, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
 
