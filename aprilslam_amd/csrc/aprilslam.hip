@@ -279,7 +279,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_cc_border");
     hipLaunchKernelGGL(k_cc_border, cgrid, dim3(128), 0, st, d->thresh.p, g, d->parent.p);
     STAGE("k_cc_flatten");
-    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, g, d->parent.p, d->sizes.p);
+    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
 
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
