@@ -26,18 +26,21 @@ TAG_OUTER, TAG_INNER = 18.0, 10.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_frames(n_distinct, seed=20250620 + 1):
+def make_frames(n_distinct, seed=20250620 + 1, with_gt=False):
     """n_distinct frames of one seeded 20-tag scene seen from a smooth camera trajectory."""
     from aprilslam_amd import synth
     rng = np.random.default_rng(seed)
     tags = synth.random_scene(W, H, NTAGS, rng, tag_size_outer=TAG_OUTER)
-    frames = []
+    frames, gts = [], []
     for i in range(n_distinct):
         a = 2 * np.pi * i / max(n_distinct, 1)
         pos = (1.5 * np.cos(a), 1.0 * np.sin(a), 2.0 * np.sin(2 * a))
         rot = (0.6 * np.sin(a), 0.8 * np.cos(a), 0.5 * np.sin(3 * a))
-        f, _ = synth.render_frame(W, H, tags, TAG_OUTER, cam_position=pos, cam_rotation_deg=rot)
+        f, gt = synth.render_frame(W, H, tags, TAG_OUTER, cam_position=pos, cam_rotation_deg=rot)
         frames.append(f)
+        gts.append(gt)
+    if with_gt:
+        return np.stack(frames), gts
     return np.stack(frames)
 
 
@@ -64,8 +67,40 @@ def stage_algorithmic_read_bytes(w, h, ch, f):
     return w * h * (1 + 5.0 / (f * f)) + (2 * w * h if ch == 3 else 0)
 
 
-def cpu_baseline(frames, K, budget_s=12.0):
-    """The CPU restatement (oracle/, 1 thread) timed on this host on a bounded sample of the same workload."""
+MM_PER_UNIT = 55.6 / 10.0  # reference config: actual_size_in_mm 55.6 for tag_size_inner 5 * size_scale 2 (config_manager.py:199-209)
+
+
+def pose_errors(T_est, T_ref):
+    """translation error in sim units and geodesic rotation angle in rad between 4x4 transforms"""
+    dt = np.linalg.norm(T_est[:3, 3] - T_ref[:3, 3])
+    R = T_est[:3, :3] @ T_ref[:3, :3].T
+    ang = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    return dt, ang
+
+
+def pose_rmse_vs_ground_truth(dets, poses, npf, gts):
+    """camera<-tag pose RMSE of the first len(gts) frames of a batch against the renderer's analytic ground truth
+    (reference src/simulation/ground_truth.py:48-90)."""
+    dt, da, start, missing = [], [], 0, 0
+    for f in range(len(gts)):
+        n = int(npf[f])
+        seen = set()
+        for k in range(start, start + n):
+            tid = int(dets["id"][k])
+            if tid in gts[f] and poses["ok"][k]:
+                a, b = pose_errors(poses["T"][k], gts[f][tid])
+                dt.append(a); da.append(b); seen.add(tid)
+        missing += len(set(gts[f]) - seen)
+        start += n
+    dt, da = np.array(dt), np.array(da)
+    return {"translation_mm": float(np.sqrt((dt ** 2).mean()) * MM_PER_UNIT), "rotation_mrad": float(np.sqrt((da ** 2).mean()) * 1e3),
+            "tags": int(len(dt)), "tags_missed": int(missing),
+            "note": "vs analytic ground truth of the synthetic renderer; includes the detector's corner noise"}
+
+
+def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
+    """The CPU restatement (oracle/, 1 thread) timed on this host on a bounded sample of the same workload.
+    With gpu=(dets, poses, npf) of the same frames it also reports how far the GPU results are from it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from aprilslam_amd.families import get_family
@@ -81,8 +116,29 @@ def cpu_baseline(frames, K, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s and n >= 8:
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp, 1 thread, %.1f s" % (n, dt)}
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp, 1 thread, %.1f s" % (n, dt)}
+    if gpu is not None:
+        dets, poses, npf = gpu
+        start, ids_equal, dcorner, dtr, drot = 0, True, 0.0, [], []
+        for f in range(len(frames)):
+            ref = O.detect_bgr(frames[f], fam)
+            m = int(npf[f])
+            mine = dets[start:start + m]
+            if [int(x) for x in mine["id"]] != [r["id"] for r in ref]:
+                ids_equal = False
+            else:
+                if ref:
+                    rv, tv, T, ok = O.solve_pnp(np.stack([r["corners"] for r in ref]), K, np.zeros(4), TAG_INNER)
+                for k, r in enumerate(ref):
+                    dcorner = max(dcorner, float(np.abs(mine["corners"][k] - r["corners"]).max()))
+                    a, b = pose_errors(poses["T"][start + k], T[k])
+                    dtr.append(a); drot.append(b)
+            start += m
+        out["gpu_vs_cpu"] = {"frames": len(frames), "ids_identical": bool(ids_equal), "max_corner_diff_px": dcorner,
+                             "pose_rmse_translation_mm": float(np.sqrt(np.mean(np.square(dtr))) * MM_PER_UNIT) if dtr else None,
+                             "pose_rmse_rotation_mrad": float(np.sqrt(np.mean(np.square(drot))) * 1e3) if drot else None}
+    return out
 
 
 def main():
@@ -94,6 +150,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=32, help="distinct rendered frames (tiled to --batch)")
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -102,9 +159,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -112,7 +174,7 @@ def main():
     from aprilslam_amd import dist as adist
 
     K = synth.camera_matrix(W, H)
-    distinct = make_frames(args.distinct, seed=20250620 + 1 + rank)  # each rank = its own stream
+    distinct, distinct_gt = make_frames(args.distinct, seed=20250620 + 1 + rank, with_gt=True)  # each rank = its own stream
     B = args.batch
     reps = (B + len(distinct) - 1) // len(distinct)
     d_frames = torch.from_numpy(distinct).to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
@@ -132,7 +194,7 @@ def main():
         dets, poses, npf = detectors[k].collect()
         if world > 1:
             obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4)
-            adist.all_gather_observations(obs, device=dev)
+            adist.all_gather_observations(obs, device=None if args.rehearse else dev)
         for kk, v in detectors[k].stage_times().items():
             kernel_ms.setdefault(kk, []).append(v)
         return dets, npf
@@ -171,13 +233,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # one extra synchronous batch (nothing else on the GPU) for un-overlapped kernel durations
     detectors[0].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[0].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
-    detectors[0].collect()
+    last = detectors[0].collect()
+    last = (last[0].copy(), last[1].copy(), last[2].copy())
     isolated = detectors[0].stage_times()
 
     if rank == 0:
@@ -218,8 +281,9 @@ def main():
             "kernel_ms_per_batch": avg,
             "kernel_ms_per_batch_isolated": isolated,
         }
+        line["pose_rmse"] = pose_rmse_vs_ground_truth(last[0], last[1], last[2], distinct_gt)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(distinct, K)
+            line["cpu_baseline"] = cpu_baseline(distinct, K, gpu=last)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
