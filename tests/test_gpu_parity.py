@@ -204,3 +204,23 @@ def test_submit_collect_pipeline_equals_blocking_call(family):
             assert np.array_equal(p0["tvec"], p1["tvec"]) and np.array_equal(p0["rvec"], p1["rvec"])
     finally:
         a.close(); b2.close()
+
+
+def test_adversarial_textures_grow_buffers_and_stay_in_parity(family):
+    """Worst-case inputs for the work buffers: salt-and-pepper blocks, a fine checkerboard (tens of thousands of
+    clusters) and a tag drowned in noise.  Buffers must grow and re-run (never truncate), results stay bit-exact."""
+    from aprilslam_amd import _lib
+    rng = np.random.default_rng(99)
+    h, w = 360, 640
+    noise = (rng.integers(0, 2, (h // 4, w // 4), dtype=np.uint8) * 255).repeat(4, 0).repeat(4, 1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    checker = ((((yy // 12) + (xx // 12)) & 1) * 255).astype(np.uint8)
+    tagf = O.bgr2gray(scene_frame(w, h, 3, 77, noise=8.0)[0])
+    frames = np.stack([noise, checker, tagf])
+    det = _lib.Detector("tagStandard41h12")
+    try:
+        dets, npf = check_stages(det, frames, family)
+        c = det.debug_counters()
+        assert c[11] == 0 and c[12] == 0 and c[13] == 0 and c[14] == 0  # the accepted run had no overflow left
+    finally:
+        det.close()
