@@ -131,6 +131,24 @@ __device__ unsigned long long g_phase_cycles[64];
 #define PHASE(k) do {} while (0)
 #endif
 
+// pixel_fetch + pixel_gray = gray_at split in two, so that callers can issue many fetches before converting
+__device__ __forceinline__ unsigned int pixel_fetch(const uint8_t *frame, const Geom &g, int x, int y)
+{
+    const uint8_t *p = frame + (size_t)y * g.stride;
+    if (g.channels == 1) return p[x];
+    unsigned int u;
+    if (x + 1 < g.w) __builtin_memcpy(&u, p + 3 * x, 4);
+    else u = (unsigned int)p[3 * x] | ((unsigned int)p[3 * x + 1] << 8) | ((unsigned int)p[3 * x + 2] << 16);
+    return u;
+}
+
+__device__ __forceinline__ int pixel_gray(unsigned int u, const Geom &g)
+{
+    if (g.channels == 1) return (int)u;
+    int b = u & 0xFF, gg = (u >> 8) & 0xFF, r = (u >> 16) & 0xFF;
+    return (b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15;  // cv2 BGR2GRAY fixed point
+}
+
 __device__ __forceinline__ int gray_at(const uint8_t *frame, const Geom &g, int x, int y)
 {
     const uint8_t *p = frame + (size_t)y * g.stride;
