@@ -269,13 +269,11 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
 
     STAGE("k_decimate_minmax");
     hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
-    STAGE("k_threshold");
-    hipLaunchKernelGGL(k_threshold, dim3((twx + 63) / 64, (g.sh + 3) / 4, B), blk, 0, st, d->dgray.p, g, d->tmin.p, d->tmax.p, d->thresh.p);
 
     STAGE("k_cc_tile");
     dim3 pgrid((g.sw + 63) / 64, (g.sh + 3) / 4, B);
     dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
-    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
+    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, d->thresh.p, d->parent.p, d->sizes.p);
     STAGE("k_cc_border");
     hipLaunchKernelGGL(k_cc_border, cgrid, dim3(128), 0, st, d->thresh.p, g, d->parent.p);
     STAGE("k_cc_flatten");

@@ -53,8 +53,7 @@ def algorithmic_bytes(kernel, w, h, ch, f):
     full = w * h * ch
     table = {
         "k_decimate_minmax": full + npix + 2 * ntile,
-        "k_threshold": npix + 2 * ntile + npix,
-        "k_cc_tile": npix + 4 * npix + 4 * npix,
+        "k_cc_tile": npix + 2 * ntile + npix + 4 * npix + 4 * npix,
         "k_cc_flatten": 4 * npix + 4 * npix + 4 * npix,
         "k_cluster_count": npix + 4 * npix + 4 * npix,
         "k_cluster_count": npix + 4 * npix + 4 * npix,
@@ -262,7 +261,7 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
                     "avg_launch_ms_isolated": isolated.get(dom), "algorithmic_bytes_per_frame": pts * 9}
-        seg_names = ("memset", "k_decimate_minmax", "k_threshold", "k_cc_tile", "k_cc_border", "k_cc_flatten",
+        seg_names = ("memset", "k_decimate_minmax", "k_cc_tile", "k_cc_border", "k_cc_flatten",
                                              "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
