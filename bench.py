@@ -214,6 +214,9 @@ def main():
         return out
 
     kernel_ms = {}
+    for k in range(P):  # set-up, not a step: first use allocates each workspace (hipMalloc of several GB)
+        detectors[k].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[k].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
+        detectors[k].collect()
     for _ in range(args.warmup):
         step()
     res = drain()
