@@ -68,7 +68,7 @@ struct asl_detector {
     DevBuf<int> slot_cluster;
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
-    DevBuf<double> scratch;
+    DevBuf<double> scratch, quadH;
     DevBuf<DetRec> dets;
     DevBuf<long long> counters;
     DevBuf<float> pnp_corners;
@@ -159,7 +159,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     (void)hipSetDevice(d->device);
     d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
-    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->dets.release();
+    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->d_codes) (void)hipFree(d->d_codes);
@@ -235,6 +235,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->slot_cluster.ensure(d->nslots);
     bad |= d->clusters.ensure(d->max_clusters);
     bad |= d->quads.ensure(d->max_clusters);
+    bad |= d->quadH.ensure((size_t)10 * d->max_clusters);
     bad |= d->points.ensure(d->max_points);
     d->stage_cap = (unsigned int)((double)g.npix * d->points_per_pixel) + 1024u;
     bad |= d->stage_rec.ensure((size_t)B * d->stage_cap);
@@ -313,10 +314,13 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, 0, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
 
-    STAGE("k_decode");
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
-    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
-                       d->maxhamming, d->refine, d->dets.p, d->max_dets, d->counters.p);
+    STAGE("k_refine");
+    hipLaunchKernelGGL(k_refine, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
+                       d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p);
+    STAGE("k_decode");
+    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
+                       d->maxhamming, d->dets.p, d->max_dets, d->counters.p);
 
     if (cam) {
         STAGE("k_pnp_dets");
