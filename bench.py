@@ -264,6 +264,14 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
                     "avg_launch_ms_isolated": isolated.get(dom), "algorithmic_bytes_per_frame": pts * 9}
+        # HBM traffic of the dominant kernel: not measurable live; taken from the committed rocprofv3 --pmc pass
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tr.get("batch_frames") == B and dom in tr["bytes_per_launch"]:
+                roof["traffic"] = tr["bytes_per_launch"][dom]
+                roof["traffic_source"] = tr["source"]
+        except Exception:
+            pass
         seg_names = ("memset", "k_decimate_minmax", "k_cc_tile", "k_cc_border", "k_cc_flatten",
                                              "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
