@@ -666,6 +666,13 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
     case 3: {
         if (bytes < total * 4) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total * 4);
         HIPCHK(hipMemcpy(dst, what == 2 ? d->parent.p : d->sizes.p, total * 4, hipMemcpyDeviceToHost));
+        {   // labels/sizes of 127 pixels are implied, not stored: fill them in for the caller
+            std::vector<uint8_t> th(total);
+            HIPCHK(hipMemcpy(th.data(), d->thresh.p, total, hipMemcpyDeviceToHost));
+            unsigned int *o = (unsigned int *)dst;
+            for (size_t i = 0; i < total; i++)
+                if (th[i] == 127) o[i] = what == 2 ? (unsigned int)(i % g.npix) : 1u;
+        }
         *n_items = total;
         return ASL_OK;
     }
