@@ -291,9 +291,10 @@ def main():
             "kernel_ms_per_batch": avg,
             "kernel_ms_per_batch_isolated": isolated,
         }
-        line["pose_rmse"] = pose_rmse_vs_ground_truth(last[0], last[1], last[2], distinct_gt)
+        nchk = min(B, len(distinct))
+        line["pose_rmse"] = pose_rmse_vs_ground_truth(last[0], last[1], last[2], distinct_gt[:nchk])
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(distinct, K, gpu=last)
+            line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

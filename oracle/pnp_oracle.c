@@ -11,8 +11,8 @@
  *   3. pose from the homography (unit first two columns, t = 2*h3/(|h1|+|h2|),
  *      third column = cross product, nearest rotation by SVD),
  *   4. Levenberg-Marquardt on the 8 pixel reprojection residuals over 6 dof.
- * Step 4 here runs to convergence in float64, i.e. to the local minimum that
- * OpenCV's 20-iteration LM approaches from the same start; parity with cv2 is
+ * Step 4 here runs to convergence in float64 within OpenCV's cap of 20 outer iterations, i.e. to the
+ * local minimum that OpenCV's LM approaches from the same start; parity with cv2 is
  * therefore tolerance-level and has no fixture ("parity unpinned").
  */
 #include "apriltag_oracle.h"
@@ -73,7 +73,8 @@ static void jacobi3(double A[9], double V[9], double d[3])
     for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0);
     for (int sweep = 0; sweep < 60; sweep++) {
         double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
-        if (off < 1e-300) break;
+        /* relative stop: below this the remaining rotations are identity in float64 */
+        if (off < 1e-15 * (fabs(A[0]) + fabs(A[4]) + fabs(A[8]))) break;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 double apq = A[3 * p + q];
@@ -251,7 +252,7 @@ static int pnp_one(const double *img /*4x2*/, const cam_t *c, double tag_size, d
     /* 4: Levenberg-Marquardt on pixel reprojection error */
     double res[8], J[48], cost = residuals(c, R, t, obj, img, res, J);
     double lambda = 1e-3;
-    for (int it = 0; it < 100; it++) {
+    for (int it = 0; it < 20; it++) { /* OpenCV caps its LM at 20 iterations as well */
         double JtJ[36], g[6];
         for (int a = 0; a < 6; a++) {
             g[a] = 0;
@@ -279,8 +280,12 @@ static int pnp_one(const double *img /*4x2*/, const cam_t *c, double tag_size, d
                 improved = 1;
                 lambda *= 0.1;
                 if (lambda < 1e-12) lambda = 1e-12;
-            } else
+            } else {
+                /* a rejected step this small means the minimum is reached: more damping cannot help */
+                double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+                if (dn < 1e-10 * (sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + 1)) break;
                 lambda *= 10;
+            }
         }
         if (!improved) break;
         double prev = cost;
