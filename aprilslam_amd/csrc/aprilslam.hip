@@ -61,7 +61,7 @@ struct asl_detector {
     // workspace
     DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
     DevBuf<unsigned int> parent, sizes;
-    DevBuf<unsigned long long> hkeys, points;
+    DevBuf<unsigned long long> hkeys, points, rootmask;
     DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
@@ -241,6 +241,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->parent.ensure(total);
     bad |= d->sizes.ensure(total);
+    bad |= d->rootmask.ensure(B * (size_t)g.sh * (size_t)((g.sw + CCT_W - 1) / CCT_W));
     bad |= d->hkeys.ensure(d->nslots);
     bad |= d->hcounts.ensure(d->nslots);
     bad |= d->class_lists.ensure((size_t)NCLASSES * d->max_clusters);
@@ -284,13 +285,17 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
 
     STAGE("k_cc_tile");
-    dim3 pgrid((g.sw + 63) / 64, (g.sh + 3) / 4, B);
     dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
-    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, d->thresh.p, d->parent.p, d->sizes.p);
+    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, d->thresh.p, d->parent.p, d->sizes.p,
+                       d->rootmask.p);
     STAGE("k_cc_border");
     hipLaunchKernelGGL(k_cc_border, cgrid, dim3(128), 0, st, d->thresh.p, g, d->parent.p);
-    STAGE("k_cc_flatten");
-    hipLaunchKernelGGL(k_cc_flatten, pgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p);
+    STAGE("k_cc_roots");
+    {
+        size_t words = (size_t)B * g.sh * cgrid.x;
+        hipLaunchKernelGGL(k_cc_roots, dim3((unsigned int)((words + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, (int)cgrid.x,
+                           d->parent.p, d->sizes.p);
+    }
 
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
@@ -677,6 +682,11 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
     case 2:
     case 3: {
         if (bytes < total * 4) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total * 4);
+        if (what == 2) {  // the pipeline keeps two-level labels (pixel -> tile root -> global root): flatten them for the caller
+            hipLaunchKernelGGL(k_cc_flatten, dim3((g.sw + 63) / 64, (g.sh + 3) / 4, (unsigned int)g.nframes), dim3(64, 4), 0, nullptr,
+                               d->thresh.p, g, d->parent.p);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipMemcpy(dst, what == 2 ? d->parent.p : d->sizes.p, total * 4, hipMemcpyDeviceToHost));
         {   // labels/sizes of 127 pixels are implied, not stored: fill them in for the caller
             std::vector<uint8_t> th(total);

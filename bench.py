@@ -54,8 +54,6 @@ def algorithmic_bytes(kernel, w, h, ch, f):
     table = {
         "k_decimate_minmax": full + npix + 2 * ntile,
         "k_cc_tile": npix + 2 * ntile + npix + 4 * npix + 4 * npix,
-        "k_cc_flatten": 4 * npix + 4 * npix + 4 * npix,
-        "k_cluster_count": npix + 4 * npix + 4 * npix,
         "k_cluster_count": npix + 4 * npix + 4 * npix,
     }
     return table.get(kernel)
@@ -272,7 +270,7 @@ def main():
                 roof["traffic_source"] = tr["source"]
         except Exception:
             pass
-        seg_names = ("memset", "k_decimate_minmax", "k_cc_tile", "k_cc_border", "k_cc_flatten",
+        seg_names = ("memset", "k_decimate_minmax", "k_cc_tile", "k_cc_border", "k_cc_roots",
                                              "k_hash_clear", "k_cluster_count", "k_cluster_filter", "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
