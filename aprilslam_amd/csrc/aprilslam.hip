@@ -62,7 +62,7 @@ struct asl_detector {
     DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
     DevBuf<unsigned int> parent, sizes;
     DevBuf<unsigned long long> hkeys, points, rootmask;
-    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor;
+    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
     DevBuf<int> slot_cluster;
@@ -224,6 +224,8 @@ static int make_geom(asl_detector *d, int n_frames, int channels, int w, int h, 
     return ASL_OK;
 }
 
+static size_t count_tiles(const Geom &g) { return (size_t)((g.sw + CNT_TW - 1) / CNT_TW) * (size_t)((g.sh + CNT_TH - 1) / CNT_TH); }
+
 static int ensure_workspace(asl_detector *d, const Geom &g)
 {
     size_t B = (size_t)g.nframes;
@@ -254,6 +256,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->stage_rec.ensure((size_t)B * d->stage_cap);
     bad |= d->stage_pos.ensure((size_t)B * d->stage_cap);
     bad |= d->frame_cursor.ensure(B);
+    bad |= d->dense_tiles.ensure(B * count_tiles(g));
     bad |= d->scratch.ensure((size_t)d->max_points * 8);
     bad |= d->dets.ensure(d->max_dets);
     bad |= d->counters.ensure(CNT__N);
@@ -301,8 +304,13 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_cluster_count");
     dim3 tgrid(B, (g.sw + CNT_TW - 1) / CNT_TW, (g.sh + CNT_TH - 1) / CNT_TH);  // workgroup = 64x16 pixel tile, frame-major
-    hipLaunchKernelGGL(k_cluster_count, tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p,
-                       d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->counters.p);
+    hipLaunchKernelGGL((k_cluster_count<CNT_TW * CNT_TH, false>), tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p,
+                       d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->dense_tiles.p,
+                       (int)tgrid.y, (int)tgrid.z, d->counters.p);
+    // tiles too dense for the small parking buffer (none in ordinary frames: the launch finds an empty list)
+    hipLaunchKernelGGL((k_cluster_count<4 * CNT_TW * CNT_TH, true>), dim3(256), blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p,
+                       d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->dense_tiles.p,
+                       (int)tgrid.y, (int)tgrid.z, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");

@@ -103,6 +103,7 @@ enum {
     CNT_CLASS1,
     CNT_CLASS2,
     CNT_CLASS3,
+    CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
     CNT__N = 16
 };
 

@@ -208,7 +208,7 @@ def test_submit_collect_pipeline_equals_blocking_call(family):
 
 def test_adversarial_textures_grow_buffers_and_stay_in_parity(family):
     """Worst-case inputs for the work buffers: salt-and-pepper blocks, a fine checkerboard (tens of thousands of
-    clusters) and a tag drowned in noise.  Buffers must grow and re-run (never truncate), results stay bit-exact."""
+    clusters), a tag drowned in noise and one-pixel stripes (the densest boundary there is).  Buffers must grow and re-run (never truncate), results stay bit-exact."""
     from aprilslam_amd import _lib
     rng = np.random.default_rng(99)
     h, w = 360, 640
@@ -216,7 +216,10 @@ def test_adversarial_textures_grow_buffers_and_stay_in_parity(family):
     yy, xx = np.mgrid[0:h, 0:w]
     checker = ((((yy // 12) + (xx // 12)) & 1) * 255).astype(np.uint8)
     tagf = O.bgr2gray(scene_frame(w, h, 3, 77, noise=8.0)[0])
-    frames = np.stack([noise, checker, tagf])
+    # 2-pixel rows (1 pixel after decimation): ~3 boundary points per pixel, more than a cluster-pass workgroup parks
+    # in its small buffer, so these tiles go through the dense-tile launch
+    stripes = ((((yy // 2) & 1) * 255)).astype(np.uint8)
+    frames = np.stack([noise, checker, tagf, stripes])
     det = _lib.Detector("tagStandard41h12")
     try:
         dets, npf = check_stages(det, frames, family)
