@@ -62,7 +62,7 @@ struct asl_detector {
     DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
     DevBuf<unsigned int> parent, sizes;
     DevBuf<unsigned long long> hkeys, points, rootmask;
-    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles;
+    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, quad_list;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
     DevBuf<int> slot_cluster;
@@ -250,6 +250,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->slot_cluster.ensure(d->nslots);
     bad |= d->clusters.ensure(d->max_clusters);
     bad |= d->quads.ensure(d->max_clusters);
+    bad |= d->quad_list.ensure(d->max_clusters);
     bad |= d->quadH.ensure((size_t)10 * d->max_clusters);
     bad |= d->points.ensure(d->max_points);
     d->stage_cap = (unsigned int)((double)g.npix * d->points_per_pixel) + 1024u;
@@ -339,13 +340,16 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, 0, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
 
+    STAGE("k_quad_compact");
+    hipLaunchKernelGGL(k_quad_compact, dim3((d->max_clusters + 1023) / 1024), dim3(1024), 0, st, d->quads.p, d->counters.p, d->max_clusters,
+                       d->quad_list.p);
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
     STAGE("k_refine");
     hipLaunchKernelGGL(k_refine, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
-                       d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p);
+                       d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p, d->quad_list.p);
     STAGE("k_decode");
     hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
-                       d->maxhamming, d->dets.p, d->max_dets, d->counters.p);
+                       d->maxhamming, d->dets.p, d->max_dets, d->counters.p, d->quad_list.p);
 
     if (cam) {
         STAGE("k_pnp_dets");
