@@ -118,18 +118,34 @@ __device__ __forceinline__ bool batch_poisoned(const long long *counters)
 // The shipped library compiles these to nothing.
 __device__ unsigned long long g_phase_cycles[64];
 #ifdef ASL_PHASE_TIMING
-#define PHASE_INIT() long long ph_t__ = clock64()
+// stamps are summed in LDS by thread 0 and leave with one atomic per phase when the workgroup ends: an atomic per
+// stamp would queue behind the other workgroups' (one address sustains ~90 atomics/us) and the next global load of
+// the wave would wait for it, charging the queueing to whichever phase touches memory first
+#define PHASE_DECL()                                                                  \
+    __shared__ unsigned long long ph_s__[16];                                         \
+    long long ph_t__ = 0;                                                             \
+    if (threadIdx.x == 0 && threadIdx.y == 0)                                         \
+        for (int ph_i__ = 0; ph_i__ < 16; ph_i__++) ph_s__[ph_i__] = 0
+#define PHASE_INIT() ph_t__ = clock64()
 #define PHASE(k)                                                                      \
     do {                                                                              \
-        if (threadIdx.x == 0) {                                                       \
+        if (threadIdx.x == 0 && threadIdx.y == 0) {                                   \
             long long now__ = clock64();                                              \
-            atomicAdd(&g_phase_cycles[k], (unsigned long long)(now__ - ph_t__));      \
+            ph_s__[(k) & 15] += (unsigned long long)(now__ - ph_t__);                 \
             ph_t__ = now__;                                                           \
         }                                                                             \
     } while (0)
+#define PHASE_FLUSH(base)                                                             \
+    do {                                                                              \
+        if (threadIdx.x == 0 && threadIdx.y == 0)                                     \
+            for (int ph_i__ = 0; ph_i__ < 16; ph_i__++)                               \
+                if (ph_s__[ph_i__]) atomicAdd(&g_phase_cycles[(base) + ph_i__], ph_s__[ph_i__]); \
+    } while (0)
 #else
+#define PHASE_DECL() do {} while (0)
 #define PHASE_INIT() do {} while (0)
 #define PHASE(k) do {} while (0)
+#define PHASE_FLUSH(base) do {} while (0)
 #endif
 
 // pixel_fetch + pixel_gray = gray_at split in two, so that callers can issue many fetches before converting
