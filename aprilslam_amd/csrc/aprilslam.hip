@@ -286,7 +286,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
 
     STAGE("k_decimate_minmax");
-    hipLaunchKernelGGL(k_decimate_minmax, dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
+    hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
 
     STAGE("k_cc_tile");
     dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
@@ -345,10 +345,10 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->quad_list.p);
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
     STAGE("k_refine");
-    hipLaunchKernelGGL(k_refine, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
+    hipLaunchKernelGGL((g.channels == 1 ? k_refine<1> : k_refine<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
                        d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p, d->quad_list.p);
     STAGE("k_decode");
-    hipLaunchKernelGGL(k_decode, dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
+    hipLaunchKernelGGL((g.channels == 1 ? k_decode<1> : k_decode<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
                        d->maxhamming, d->dets.p, d->max_dets, d->counters.p, d->quad_list.p);
 
     if (cam) {

@@ -148,36 +148,37 @@ __device__ unsigned long long g_phase_cycles[64];
 #define PHASE_FLUSH(base) do {} while (0)
 #endif
 
-// pixel_fetch + pixel_gray = gray_at split in two, so that callers can issue many fetches before converting
-__device__ __forceinline__ unsigned int pixel_fetch(const uint8_t *frame, const Geom &g, int x, int y)
+// pixel_fetch + pixel_gray = gray_at split in two, so that callers can issue many fetches before converting.
+// Branch-free on purpose (these sit in the innermost loops of the per-quad kernels): one possibly unaligned 4-byte
+// fetch covers B, G, R (the 4th byte is the next pixel's B); for the last pixel of a row the fetch starts one byte
+// earlier and is shifted, so it never leaves the frame.  Offsets are 32-bit: a frame is at most 16384 x 16384 x 3 bytes.
+// CH (1 = gray, 3 = BGR) is a template parameter of the kernels on this path, so no branch on it splits their loops.
+template <int CH>
+__device__ __forceinline__ unsigned int pixel_fetch(const uint8_t *frame, const Geom &g, int x, int y, unsigned int *shift)
 {
-    const uint8_t *p = frame + (size_t)y * g.stride;
-    if (g.channels == 1) return p[x];
+    // returns the raw fetch; *shift (0 or 8) is applied by pixel_gray, so nothing here depends on the loaded value
+    // and a caller can issue many fetches back to back before the first conversion waits for memory
+    if (CH == 1) { *shift = 0; return frame[(unsigned int)y * (unsigned int)g.stride + (unsigned int)x]; }
+    const unsigned int sh = (x + 1 < g.w) ? 0u : 1u;
     unsigned int u;
-    if (x + 1 < g.w) __builtin_memcpy(&u, p + 3 * x, 4);
-    else u = (unsigned int)p[3 * x] | ((unsigned int)p[3 * x + 1] << 8) | ((unsigned int)p[3 * x + 2] << 16);
+    __builtin_memcpy(&u, frame + ((unsigned int)y * (unsigned int)g.stride + 3u * (unsigned int)x - sh), 4);
+    *shift = 8u * sh;
     return u;
 }
 
-__device__ __forceinline__ int pixel_gray(unsigned int u, const Geom &g)
+template <int CH>
+__device__ __forceinline__ int pixel_gray(unsigned int u, unsigned int shift)
 {
-    if (g.channels == 1) return (int)u;
+    if (CH == 1) return (int)u;
+    u >>= shift;
     int b = u & 0xFF, gg = (u >> 8) & 0xFF, r = (u >> 16) & 0xFF;
     return (b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15;  // cv2 BGR2GRAY fixed point
 }
 
+template <int CH>
 __device__ __forceinline__ int gray_at(const uint8_t *frame, const Geom &g, int x, int y)
 {
-    const uint8_t *p = frame + (size_t)y * g.stride;
-    if (g.channels == 1) return p[x];
-    int b, gg, r;
-    if (x + 1 < g.w) {
-        // one (possibly unaligned) 4-byte fetch instead of three byte loads; the 4th byte is the next pixel's B
-        unsigned int u;
-        __builtin_memcpy(&u, p + 3 * x, 4);
-        b = u & 0xFF; gg = (u >> 8) & 0xFF; r = (u >> 16) & 0xFF;
-    } else {
-        b = p[3 * x]; gg = p[3 * x + 1]; r = p[3 * x + 2];
-    }
-    return (b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15;  // cv2 BGR2GRAY fixed point
+    unsigned int sh;
+    unsigned int u = pixel_fetch<CH>(frame, g, x, y, &sh);
+    return pixel_gray<CH>(u, sh);
 }
