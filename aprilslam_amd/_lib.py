@@ -37,7 +37,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -69,6 +69,8 @@ def load():
     L.asl_detect_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_bgr_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_batch_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.asl_detect_batch_pose_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, dp, dp, i32, C.c_double, vp, vp, i32,
+                                           C.POINTER(i32), C.POINTER(i32)]
     L.asl_detect_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double,
                                           vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.asl_submit_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double]
@@ -113,9 +115,10 @@ class Detector:
             pass
 
     # -- host images ------------------------------------------------------------------
-    def detect_host(self, images, max_per_frame=256, channels=None):
+    def detect_host(self, images, max_per_frame=256, channels=None, K=None, dist=None, tag_size=0.0):
         """images: (H,W) / (H,W,3) uint8 array, or (B,H,W[,3]); pass channels=1 for a gray batch whose W is 3.
-        Returns (dets, n_per_frame)."""
+        Returns (dets, n_per_frame); with a camera matrix K the per-tag PnP runs in the same submission
+        (asl_detect_batch_pose_u8) and the result is (dets, poses, n_per_frame)."""
         a = np.ascontiguousarray(images, dtype=np.uint8)
         if a.ndim == 2:
             a = a[None]
@@ -135,6 +138,19 @@ class Detector:
         out = np.empty(cap, dtype=DET_DTYPE)
         npf = (C.c_int * B)()
         n = C.c_int()
+        if K is not None:
+            dp = C.POINTER(C.c_double)
+            Kc = np.ascontiguousarray(K, dtype=np.float64)
+            dc = np.ascontiguousarray(np.zeros(0) if dist is None else dist, dtype=np.float64).ravel()
+            if len(dc) not in (0, 4, 5):
+                raise ValueError("dist must have 0, 4 or 5 coefficients")
+            poses = np.empty(cap, dtype=POSE_DTYPE)
+            check(self._L.asl_detect_batch_pose_u8(self._h, ptrs, B, ch, W, H, stride, Kc.ctypes.data_as(dp),
+                                                   dc.ctypes.data_as(dp) if len(dc) else None, len(dc), float(tag_size),
+                                                   out.ctypes.data, poses.ctypes.data, cap, npf, C.byref(n)))
+            if n.value > cap:
+                return self.detect_host(images, (n.value + B - 1) // B + 1, channels, K, dist, tag_size)
+            return out[:n.value], poses[:n.value], np.array(list(npf), dtype=np.int64)
         check(self._L.asl_detect_batch_u8(self._h, ptrs, B, ch, W, H, stride, out.ctypes.data, cap, npf, C.byref(n)))
         if n.value > cap:
             return self.detect_host(images, max_per_frame=(n.value + B - 1) // B + 1, channels=channels)

@@ -642,6 +642,29 @@ extern "C" int asl_detect_batch_u8(asl_detector *d, const uint8_t *const *frames
     return collect_batch(d, out, nullptr, max_out, n_per_frame, n_out);
 }
 
+extern "C" int asl_detect_batch_pose_u8(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
+                                        const double *K, const double *dist, int n_dist, double tag_size, asl_detection *out, asl_pose *poses,
+                                        int max_out, int *n_per_frame, int *n_out)
+{
+    if (!d || !frames || !K || !poses) return fail(ASL_EINVAL, "NULL detector, frames, K or poses");
+    if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
+    if (n_dist && !dist) return fail(ASL_EINVAL, "dist is NULL but n_dist = %d", n_dist);
+    HIPCHK(hipSetDevice(d->device));
+    Geom g;
+    size_t pitch = (size_t)stride * (size_t)h;
+    int rc = make_geom(d, n_frames, channels, w, h, stride, pitch, &g);
+    if (rc) return rc;
+    if (d->in.ensure(pitch * (size_t)n_frames)) return fail(ASL_ENOMEM, "input staging allocation failed");
+    for (int i = 0; i < n_frames; i++) {
+        if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
+        HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
+    }
+    CamDev cam = make_cam(K, dist, n_dist, tag_size);
+    int rcs = submit_batch(d, d->in.p, g, nullptr, &cam);
+    if (rcs) return rcs;
+    return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
+}
+
 extern "C" int asl_detect_gray_u8(asl_detector *d, const uint8_t *gray, int w, int h, int stride, asl_detection *out, int max_out, int *n_out)
 {
     const uint8_t *fr[1] = {gray};

@@ -42,13 +42,23 @@ class TagDetector:
             return sorted(self.detector.detect(a), key=lambda d: d['id'])
         if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
             raise ValueError("expected an (H, W, 3) uint8 BGR image")
-        dets, _ = self.detector._det.detect_host(np.ascontiguousarray(a))
+        # the poses are solved in the same device submission (asl_detect_batch_pose_u8) and ride along under a
+        # private key, so that get_pose() of these detections needs no second trip to the GPU; the arithmetic is
+        # the one get_pose() does on its own (float32-rounded corners -> asl_solve_pnp_batch), bit for bit
+        dets, poses, _ = self.detector._det.detect_host(np.ascontiguousarray(a), K=self.camera_matrix, dist=self._dist(),
+                                                        tag_size=self.tag_size)
         out = [{"hamming": int(d["hamming"]), "margin": float(d["margin"]), "id": int(d["id"]),
-                "center": np.array(d["center"]), "lb-rb-rt-lt": np.array(d["corners"])} for d in dets]
+                "center": np.array(d["center"]), "lb-rb-rt-lt": np.array(d["corners"]),
+                "_pose": (np.array(d["corners"]), self._pose_key(), bool(p["ok"]), np.array(p["rvec"]), np.array(p["tvec"]))}
+               for d, p in zip(dets, poses)]
         return sorted(out, key=lambda d: d['id'])
 
     def get_pose(self, detection):
         """(retval, rvec(3,1), tvec(3,1), T 4x4) of one detection (tag_detector.py:30-43)."""
+        cached = detection.get('_pose') if isinstance(detection, dict) else None
+        if cached is not None and cached[1] == self._pose_key() and np.array_equal(cached[0], detection['lb-rb-rt-lt']):
+            rv, tv = cached[3].reshape(3, 1).copy(), cached[4].reshape(3, 1).copy()
+            return cached[2], rv, tv, self.transformation(rv, tv)
         corners = np.array(detection['lb-rb-rt-lt'], dtype=np.float32)
         rvec, tvec, _, ok = self.detector._det.solve_pnp(corners[None], self.camera_matrix, self._dist(), self.tag_size)
         rv, tv = rvec[0].reshape(3, 1), tvec[0].reshape(3, 1)
@@ -95,6 +105,10 @@ class TagDetector:
         return image
 
     # -- batched forms ------------------------------------------------------------------
+    def _pose_key(self):
+        """what a cached pose depends on besides the corners: tag size and intrinsics, by value"""
+        return (float(self.tag_size), np.asarray(self.camera_matrix, dtype=np.float64).tobytes(), self._dist().tobytes())
+
     def _dist(self):
         d = np.asarray(self.dist_coeffs, dtype=np.float64).ravel()
         if len(d) not in (0, 4, 5):

@@ -88,6 +88,14 @@ int asl_detect_batch_u8(asl_detector *det, const uint8_t *const *frames, int n_f
                         int w, int h, int stride, asl_detection *out, int max_out, int *n_per_frame,
                         int *n_out);
 
+/* asl_detect_batch_u8 with the per-tag PnP (asl_solve_pnp_batch) fused into the same submission: what the reference
+   does per frame with detector.detect + one cv2.solvePnP per tag (tag_detector.py:26,41) in a single call.
+   poses[i] belongs to out[i]; K is 9 doubles row-major; dist holds n_dist = 0, 4 or 5 coefficients. */
+int asl_detect_batch_pose_u8(asl_detector *det, const uint8_t *const *frames, int n_frames, int channels,
+                             int w, int h, int stride, const double *K, const double *dist, int n_dist,
+                             double tag_size, asl_detection *out, asl_pose *poses, int max_out,
+                             int *n_per_frame, int *n_out);
+
 /* Same, frames already resident in HBM: frame i starts at d_frames + i*frame_pitch.
    If K is non-NULL the per-tag PnP (asl_solve_pnp_batch) runs on the device in the same
    submission and poses[i] belongs to out[i].  Results are written to HOST memory; the call

@@ -120,6 +120,27 @@ def test_device_resident_batch_with_pose(gpu_detector, family):
     assert np.array_equal(poses["tvec"], tv) and np.array_equal(poses["rvec"], rv) and poses["ok"].all()
 
 
+def test_tag_detector_detect_carries_the_pose_get_pose_would_compute(family):
+    """TagDetector.detect solves the poses in the same submission (asl_detect_batch_pose_u8); get_pose of such a
+    detection must return exactly what the stand-alone asl_solve_pnp_batch call returns for its corners."""
+    from aprilslam_amd.tag_detector import TagDetector
+    frame, _ = scene_frame(1280, 720, 20, 11)
+    K = synth.camera_matrix(1280, 720)
+    for dist in (np.zeros((4, 1)), np.array([0.05, -0.02, 0.001, -0.0005, 0.01])):
+        td = TagDetector({"camera_matrix": K, "dist_coeffs": dist}, tag_size=10.0)
+        dets = td.detect(frame)
+        assert len(dets) == 20
+        for d in dets:
+            ok, rv, tv, T = td.get_pose(d)
+            plain = {k: v for k, v in d.items() if k != "_pose"}
+            ok2, rv2, tv2, T2 = td.get_pose(plain)
+            assert ok == ok2 and np.array_equal(rv, rv2) and np.array_equal(tv, tv2) and np.array_equal(T, T2)
+        # a detection whose corners were edited falls back to the stand-alone solve
+        e = dict(dets[0]); e["lb-rb-rt-lt"] = dets[0]["lb-rb-rt-lt"] + 1.0
+        assert not np.array_equal(td.get_pose(e)[2], td.get_pose(dets[0])[2])
+        td.detector._det.close()
+
+
 def test_errors_are_loud(gpu_detector):
     from aprilslam_amd import _lib
     with pytest.raises(_lib.AslError):
