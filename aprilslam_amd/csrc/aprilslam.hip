@@ -278,7 +278,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
 static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
 {
     dim3 blk(64, 4, 1);
-    int twx = (g.sw + TILESZ - 1) / TILESZ, thx = (g.sh + TILESZ - 1) / TILESZ;
+    int thx = (g.sh + TILESZ - 1) / TILESZ;
     unsigned int B = (unsigned int)g.nframes;
     d->nev = 0;
     STAGE("memset");
@@ -286,7 +286,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
 
     STAGE("k_decimate_minmax");
-    hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((twx + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
+    hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((g.sw + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
 
     STAGE("k_cc_tile");
     dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
