@@ -149,6 +149,13 @@ def test_errors_are_loud(gpu_detector):
         _lib.Detector("tagStandard41h12", decimate=1.5)
     with pytest.raises(_lib.AslError):
         _lib.Detector("tagStandard41h12", blur=0.8)
+    img = np.zeros((64, 64), np.uint8)
+    with pytest.raises(ValueError):
+        gpu_detector.detect_host(img, K=np.eye(3), dist=np.zeros(3))       # 3 distortion coefficients
+    with pytest.raises(_lib.AslError):
+        gpu_detector.detect_host(np.zeros((4, 4), np.uint8))               # smaller than the 8x8 minimum
+    with pytest.raises(_lib.AslError):
+        gpu_detector.detect_device(0, 1, 3, 64, 64)                        # NULL device pointer
 
 
 def test_gn_backend_matches_cpu_restatement(gpu_detector):
