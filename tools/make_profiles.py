@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turn one round's raw measurement files (gpurun_out/) into the committed summaries under profiles/.
+
+Inputs (produced on the GPU box, see DESIGN.md section 5 for the commands):
+  gpurun_out/bench_final.log            python bench.py                               (last line = the JSON)
+  gpurun_out/prof_f/f_kernel_stats.csv  rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+  gpurun_out/pmc_{fetch,write,sq1,sq2}.csv   tools/pmc_summary.py over rocprofv3 --pmc passes of
+                                        python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline
+usage: make_profiles.py <round tag, e.g. r01>"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+NAMES = {"void k_cluster_count<1024, false>": "k_cluster_count", "void k_cluster_count<4096, true>": "k_cluster_count<dense>",
+         "void k_decimate_minmax<3>": "k_decimate_minmax", "void k_decode<3>": "k_decode", "void k_refine<3>": "k_refine",
+         "void k_fit_quads<64, true, 2>": "k_fit_quads<0>", "void k_fit_quads<64, true, 4>": "k_fit_quads<1>",
+         "void k_fit_quads<256, true, 4>": "k_fit_quads<2>", "void k_fit_quads<256, false, 0>": "k_fit_quads<3>"}
+
+
+def table(path):
+    rows = list(csv.reader(open(path)))
+    hdr = rows[0]
+    return hdr, {r[0]: dict(zip(hdr[1:], [float(x) for x in r[1:]])) for r in rows[1:]}
+
+
+def ours(k):
+    return not (k.startswith("__amd") or "at::native" in k)
+
+
+bench = json.loads(open(os.path.join(G, "bench_final.log")).read().strip().splitlines()[-1])
+B = bench["config"]["batch_frames"]
+json.dump(bench, open(os.path.join(P, tag + "_bench_default.json"), "w"))
+
+dst = os.path.join(P, tag + "_f_kernel_stats.csv")
+shutil.copy(os.path.join(G, "prof_f", "f_kernel_stats.csv"), dst)
+body = open(dst).read()
+open(dst, "w").write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   (B=%d, pipeline 2; 10 launches "
+                     "per kernel = 2 set-up + 2 warm-up + 5 timed + 1 isolated; only warm-up/timed launches overlap with the other workspace)\n" % B + body)
+
+_, f = table(os.path.join(G, "pmc_fetch.csv"))
+_, w = table(os.path.join(G, "pmc_write.csv"))
+bpl = {}
+with open(os.path.join(P, tag + "_g_pmc_fetch_write_per_kernel.csv"), "w") as o:
+    o.write("# rocprofv3 --pmc FETCH_SIZE (second run: --pmc WRITE_SIZE) -- python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline\n")
+    o.write("# one launch = %d frames of 1280x720 BGR.  Counter unit: KB, average per launch.  gfx950: FETCH_SIZE counts 64 B per 128-B request on "
+            "wide (16 B/lane) coalesced streams (x2 to compare with bytes); byte/dword gathers are uncalibrated, values are raw.\n" % B)
+    o.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,raw_bytes_per_frame(fetch+write)\n")
+    for k in sorted(f):
+        if not ours(k):
+            continue
+        fv, wv = f[k]["FETCH_SIZE"], w.get(k, {}).get("WRITE_SIZE", 0.0)
+        nm = NAMES.get(k, k)
+        bpl[nm] = (fv + wv) * 1024.0
+        o.write("%s,%d,%.1f,%.1f,%.0f\n" % (nm, int(f[k]["launches"]), fv, wv, (fv + wv) * 1024 / B))
+json.dump({"source": "profiles/%s_g_pmc_fetch_write_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, B=%d)" % (tag, B),
+           "note": "raw FETCH_SIZE+WRITE_SIZE bytes per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950",
+           "batch_frames": B, "bytes_per_launch": bpl}, open(os.path.join(P, tag + "_traffic.json"), "w"), indent=1)
+
+h1, a = table(os.path.join(G, "pmc_sq1.csv"))
+h2, b = table(os.path.join(G, "pmc_sq2.csv"))
+c1, c2 = h1[2:], h2[2:]
+iso = bench["kernel_ms_per_batch_isolated"]
+with open(os.path.join(P, tag + "_h_sq_counters_per_kernel.csv"), "w") as o:
+    o.write("# rocprofv3 --pmc <8 SQ counters> (two passes) -- python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline ; B=%d frames "
+            "per launch, averages per launch\n" % B)
+    o.write("# valu_floor_ms = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz): the time the launch would take if the vector ALUs never idled; "
+            "isolated_ms from the same build (bench.py kernel_ms_per_batch_isolated)\n")
+    o.write("kernel," + ",".join(c1 + c2) + ",valu_floor_ms,isolated_ms,valu_busy_frac\n")
+    for k in sorted(a):
+        if not ours(k):
+            continue
+        nm = NAMES.get(k, k)
+        v = a[k]["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9) * 1e3
+        t = iso.get(nm)
+        o.write(nm + "," + ",".join("%.0f" % a[k][c] for c in c1) + "," + ",".join("%.0f" % b.get(k, {}).get(c, 0) for c in c2) +
+                ",%.3f,%s,%s\n" % (v, ("%.3f" % t) if t else "", ("%.2f" % (v / t)) if t else ""))
+print("value", bench["value"], "stage", bench["stage_threshold_segmentation"], "traffic/frame", sum(bpl.values()) / B)
