@@ -328,7 +328,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<1>");
-    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS1_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS1_CAP, st, d->clusters.p,
+    // two wavefronts per cluster here: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
+    hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), 64 * CLASS1_CAP, st, d->clusters.p,
                        d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<2>");
