@@ -323,7 +323,10 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
 
     // one launch per size class; each walks its own cluster list (grid-stride)
     const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
-    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, 16384u);
+    // grid-stride kernels over device-side work lists: many more workgroups than fit on the chip, so the heavy-tailed
+    // per-cluster / per-quad costs balance out (workgroups without work leave at once)
+    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
+    unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
     STAGE("k_fit_quads<0>");
     hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
@@ -333,7 +336,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<2>");
-    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
                        d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<3>");
@@ -344,7 +347,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_quad_compact");
     hipLaunchKernelGGL(k_quad_compact, dim3((d->max_clusters + 1023) / 1024), dim3(1024), 0, st, d->quads.p, d->counters.p, d->max_clusters,
                        d->quad_list.p);
-    unsigned int dgrid = std::min<unsigned int>(d->max_clusters, 8192u);
+    unsigned int dgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(8192u, 64u * B));
     STAGE("k_refine");
     hipLaunchKernelGGL((g.channels == 1 ? k_refine<1> : k_refine<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
                        d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p, d->quad_list.p);
