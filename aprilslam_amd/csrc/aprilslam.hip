@@ -190,15 +190,14 @@ extern "C" int asl_stage_times(asl_detector *d, const char **names, float *ms, i
     return ASL_OK;
 }
 
-// tags carried per 64-lane wave by the PnP kernels (see k_pnp.inc); ASL_PNP_LPW overrides for tuning
-static int pnp_lpw()
+// Tags carried per 64-lane wave by the PnP kernels (see k_pnp.inc): few, so that a wave is not held up by the slowest
+// of 64 tags, but not so few that the waves outnumber what the 1024 SIMDs run at once.  `expected` = tags in the launch.
+static int pnp_lpw(size_t expected)
 {
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("ASL_PNP_LPW");
-        int x = e ? atoi(e) : 16;
-        v = x < 1 ? 1 : (x > 64 ? 64 : x);
-    }
+    const char *e = getenv("ASL_PNP_LPW");  // tuning override
+    if (e) { int x = atoi(e); return x < 1 ? 1 : (x > 64 ? 64 : x); }
+    int v = 8;
+    while (v < 64 && (size_t)v * 640 < expected) v <<= 1;
     return v;
 }
 
@@ -357,7 +356,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
 
     if (cam) {
         STAGE("k_pnp_dets");
-        hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + pnp_lpw() - 1) / pnp_lpw()), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam, pnp_lpw());
+        const int lpw = pnp_lpw(d->nd_guess ? d->nd_guess : (size_t)20 * B);  // detections of the previous batch, else a guess
+        hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + lpw - 1) / lpw), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam, lpw);
     }
     if (d->profiling && d->nev <= MAX_STAGES) HIPCHK(hipEventRecord(d->ev[d->nev], st));
     HIPCHK(hipGetLastError());
@@ -694,7 +694,7 @@ extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const 
     CamDev cam = make_cam(K, dist, n_dist, tag_size);
     HIPCHK(hipMemcpy(d->pnp_corners.p, corners, sizeof(float) * 8 * (size_t)N, hipMemcpyHostToDevice));
     double *dr = d->pnp_out.p, *dt = dr + 3 * (size_t)N, *dT = dt + 3 * (size_t)N;
-    hipLaunchKernelGGL(k_pnp_batch, dim3((N + pnp_lpw() - 1) / pnp_lpw()), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p, pnp_lpw());
+    hipLaunchKernelGGL(k_pnp_batch, dim3((N + pnp_lpw((size_t)N) - 1) / pnp_lpw((size_t)N)), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p, pnp_lpw((size_t)N));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(rvec, dr, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tvec, dt, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));
