@@ -147,8 +147,8 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
         return fail(ASL_EDEVICE, "hipMemcpy(code book) failed");
     }
     d->fam.codes = d->d_codes;
-    // class-2 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS2_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS2_CAP);
+    // class-3 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS3_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS3_CAP);
     *out = d;
     return ASL_OK;
 }
@@ -339,8 +339,12 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<3>");
+    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), 64 * CLASS3_CAP, st, d->clusters.p,
+                       d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g,
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+    STAGE("k_fit_quads<4>");
     hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
-                       d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, 0, d->points.p, d->dgray.p, g,
+                       d->class_lists.p + (size_t)4 * d->max_clusters, d->counters.p, 4, d->max_clusters, 0, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
 
     STAGE("k_quad_compact");

@@ -12,11 +12,13 @@
 #define COS_CRITICAL_RAD 0.984807753012208 /* cos(10 deg) */
 #define HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define HASH_MAX_PROBE 512
-#define NCLASSES 4
-// size classes of the quad fit: points <= 128, <= 256, <= 1024 (all-LDS), larger (global slab)
+#define NCLASSES 5
+// size classes of the quad fit: points <= 128, <= 256, <= 512, <= 1024 (all-LDS), larger (global slab).  The LDS slab of a
+// workgroup is 64 bytes x cap, so every halving of the cap doubles the workgroups a CU can hold.
 #define CLASS0_CAP 128
 #define CLASS1_CAP 256
-#define CLASS2_CAP 1024
+#define CLASS2_CAP 512
+#define CLASS3_CAP 1024
 
 // growable device buffer
 template <typename T>
@@ -90,19 +92,17 @@ struct CamDev {
 enum {
     CNT_NCLUSTERS = 0,  // surviving clusters
     CNT_NPOINTS,        // points reserved for surviving clusters
-    CNT_NSCRATCH,       // points reserved in the large-cluster scratch pool
     CNT_NDETS,          // detections appended
     CNT_OVERFLOW_HASH,
     CNT_OVERFLOW_POINTS,
     CNT_OVERFLOW_CLUSTERS,
-    CNT_OVERFLOW_SCRATCH,
     CNT_OVERFLOW_DETS,
     CNT_NQUADS,
-    CNT_TOTAL_EMITTED,
     CNT_CLASS0,  // clusters per size class (lists consumed by the fit kernels)
     CNT_CLASS1,
     CNT_CLASS2,
     CNT_CLASS3,
+    CNT_CLASS4,
     CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
     CNT__N = 16
 };

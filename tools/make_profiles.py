@@ -21,7 +21,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 NAMES = {"void k_cluster_count<1024, false>": "k_cluster_count", "void k_cluster_count<4096, true>": "k_cluster_count<dense>",
          "void k_decimate_minmax<3>": "k_decimate_minmax", "void k_decode<3>": "k_decode", "void k_refine<3>": "k_refine",
          "void k_fit_quads<64, true, 2>": "k_fit_quads<0>", "void k_fit_quads<128, true, 2>": "k_fit_quads<1>",
-         "void k_fit_quads<256, true, 4>": "k_fit_quads<2>", "void k_fit_quads<256, false, 0>": "k_fit_quads<3>"}
+         "void k_fit_quads<256, true, 2>": "k_fit_quads<2>", "void k_fit_quads<256, true, 4>": "k_fit_quads<3>",
+         "void k_fit_quads<256, false, 0>": "k_fit_quads<4>"}
 
 
 def table(path):
