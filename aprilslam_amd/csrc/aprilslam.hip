@@ -292,7 +292,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, d->thresh.p, d->parent.p, d->sizes.p,
                        d->rootmask.p);
     STAGE("k_cc_border");
-    hipLaunchKernelGGL(k_cc_border, cgrid, dim3(128), 0, st, d->thresh.p, g, d->parent.p);
+    hipLaunchKernelGGL(k_cc_border, dim3((cgrid.x + 1) / 2, cgrid.y, cgrid.z), dim3(256), 0, st, d->thresh.p, g, d->parent.p);
     STAGE("k_cc_roots");
     {
         size_t words = (size_t)B * g.sh * cgrid.x;
