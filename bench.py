@@ -190,7 +190,9 @@ def main():
     def finish(k):
         dets, poses, npf = detectors[k].collect()
         if world > 1:
-            obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4)
+            if "obs" not in state:
+                state["obs"] = adist.pinned_observation_buffer(B, NTAGS + 4) if not args.rehearse else None
+            obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4, out=state["obs"])
             adist.all_gather_observations(obs, device=None if args.rehearse else dev)
         for kk, v in detectors[k].stage_times().items():
             kernel_ms.setdefault(kk, []).append(v)

@@ -52,3 +52,29 @@ def test_random_scenes_end_to_end(family, decimate):
                     assert np.abs(mp["rvec"] - orv).max() <= 1e-6 and np.abs(mp["tvec"] - otv).max() <= 1e-6
     finally:
         det.close()
+
+
+def test_observation_gather_device_path(monkeypatch):
+    """The device path of all_gather_observations (cached device and page-locked buffers, asynchronous copies) with
+    the collective itself replaced by a local stand-in -- a one-GPU box cannot host two RCCL ranks.  The gloo tests
+    cover the real collective on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+    from aprilslam_amd import dist as adist
+
+    def fake_all_gather(outs, t):
+        for r, o in enumerate(outs):
+            o.copy_(t + r)
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda: 3)
+    monkeypatch.setattr(dist, "all_gather", fake_all_gather)
+    dev = torch.device("cuda", 0)
+    buf = adist.pinned_observation_buffer(16, 24)
+    rng = np.random.default_rng(5)
+    for it in range(3):  # second and third call reuse the cached buffers
+        buf[...] = rng.normal(size=buf.shape)
+        got = adist.all_gather_observations(buf, device=dev)
+        assert got.shape == (3,) + buf.shape
+        for r in range(3):
+            assert np.array_equal(got[r], buf + r)
