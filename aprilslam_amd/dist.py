@@ -73,11 +73,12 @@ def pinned_observation_buffer(n_frames, max_tags):
     return t.numpy()
 
 
-def all_gather_observations(local_obs, device=None):
+def all_gather_observations(local_obs, device=None, wait=True):
     """All ranks contribute an equally shaped record block; returns (world, n_frames, max_tags, OBS_WIDTH)
     as a numpy array, identical on every rank.  Falls back to the local block when not distributed.
-    With a CUDA `device` the gathered block comes back through a cached page-locked buffer: the returned array
-    is a view of it, valid until the next call with the same shape."""
+    With a CUDA `device` the gathered block comes back through cached page-locked buffers (two, used alternately):
+    the returned array is a view of one, valid until the call after next with the same shape.  wait=False returns
+    (array, event) right after enqueueing the read-back; the array may be read once event.synchronize() returned."""
     import torch
     import torch.distributed as dist
 
@@ -92,15 +93,22 @@ def all_gather_observations(local_obs, device=None):
     key = (str(device), world) + tuple(t.shape)
     bufs = _gather_cache.get(key)
     if bufs is None:
-        bufs = (torch.empty(tuple(t.shape), dtype=t.dtype, device=device),
-                torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device),
-                torch.empty((world,) + tuple(t.shape), dtype=t.dtype).pin_memory())
+        bufs = {"d_in": torch.empty(tuple(t.shape), dtype=t.dtype, device=device),
+                "d_out": torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device),
+                "h_out": [torch.empty((world,) + tuple(t.shape), dtype=t.dtype).pin_memory() for _ in range(2)],
+                "turn": 0}
         _gather_cache[key] = bufs
-    d_in, d_out, h_out = bufs
+    d_in, d_out = bufs["d_in"], bufs["d_out"]
+    h_out = bufs["h_out"][bufs["turn"]]
+    bufs["turn"] ^= 1
     d_in.copy_(t, non_blocking=True)
     # one flat all-gather; the output rows are views of one contiguous block
     dist.all_gather([d_out[r] for r in range(world)], d_in)
     h_out.copy_(d_out, non_blocking=True)
+    if not wait:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return h_out.numpy(), ev
     torch.cuda.current_stream(device).synchronize()
     return h_out.numpy()
 

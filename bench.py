@@ -192,8 +192,15 @@ def main():
         if world > 1:
             if "obs" not in state:
                 state["obs"] = adist.pinned_observation_buffer(B, NTAGS + 4) if not args.rehearse else None
+            if state.get("gather_ev") is not None:
+                # the previous step's exchange is complete: its H2D no longer reads the pack buffer and its gathered
+                # block has landed in host memory
+                state["gather_ev"].synchronize()
             obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4, out=state["obs"])
-            adist.all_gather_observations(obs, device=None if args.rehearse else dev)
+            if args.rehearse:
+                adist.all_gather_observations(obs, device=None)
+            else:  # read-back of the gathered block overlaps the next step (it is consumed one step later)
+                _, state["gather_ev"] = adist.all_gather_observations(obs, device=dev, wait=False)
         for kk, v in detectors[k].stage_times().items():
             kernel_ms.setdefault(kk, []).append(v)
         return dets, npf
