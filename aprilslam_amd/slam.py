@@ -23,7 +23,31 @@ class _NullVisualizer:
         pass
 
 
+def fuse_camera_pose(nodes, visible_ids):
+    """Every visible tag that is already a node votes with world @ local (the camera pose it implies), weighted by
+    1 / chain length; the votes are averaged ELEMENT-WISE (the result is in general not orthonormal -- that is the
+    reference's estimator and it is reproduced bit for bit: same operand order, same accumulation order).
+    Side effect, as in the reference: node.visible is refreshed for all nodes."""
+    for tag in nodes.values():
+        tag.visible = False
+    acc = np.zeros((4, 4))
+    norm = 0
+    for tag_id in visible_ids:
+        tag = nodes.get(tag_id)
+        if tag is None:
+            continue
+        tag.visible = True
+        vote = np.matmul(tag.world, tag.local)
+        acc += vote / tag.weight
+        norm += 1 / tag.weight
+    if norm == 0:
+        return None
+    return acc / norm
+
+
 class SLAM:
+    """Facade with the reference's constructor and methods (slam.py:9-97); detector and visualiser can be injected."""
+
     def __init__(self, logger, camera_params, tag_type="tagStandard41h12", tag_size=0.06, detector=None,
                  visualizer=None, device=0):
         self.logger = logger
@@ -53,36 +77,25 @@ class SLAM:
         return self.my_pose()
 
     def my_pose(self):
-        """Weighted element-wise mean of world @ local over the visible nodes (slam.py:36-63)."""
-        if not self.visible_tags:
+        """Camera pose in the world frame of the graph, or None when no visible tag is in the graph yet.
+        Same arithmetic as the reference (slam.py:36-63), see `fuse_camera_pose`."""
+        seen = self.visible_tags
+        if not seen:
             return None
-        nodes = self.graph.get_nodes()
-        for node in nodes.values():
-            node.visible = False
-        T_sum = np.zeros((4, 4))
-        count = 0
-        for tag_id in self.visible_tags:
-            node = nodes.get(tag_id)
-            if node is None:
-                continue
-            node.visible = True
-            T = np.matmul(node.world, node.local)
-            T_sum += T / node.weight
-            count += 1 / node.weight
-        if count == 0:
-            return None
-        T_avg = T_sum / count
-        self.graph.estimated_pose = T_avg
-        return T_avg
+        estimate = fuse_camera_pose(self.graph.get_nodes(), seen)
+        if estimate is not None:
+            self.graph.estimated_pose = estimate
+        return estimate
 
     def average_distance_to_nodes(self):
+        """Mean distance camera <-> tag over ALL nodes of the graph (0 for an empty graph), slam.py:65-80."""
         nodes = self.graph.get_nodes()
-        if not nodes:
+        if len(nodes) == 0:
             return 0
-        total = 0
-        for node in nodes.values():
-            total += np.linalg.norm(node.local[:3, 3])
-        return total / len(nodes)
+        dist_sum = 0
+        for tag in nodes.values():
+            dist_sum += np.linalg.norm(tag.local[:3, 3])
+        return dist_sum / len(nodes)
 
     @property
     def coordinate_id(self):
