@@ -141,8 +141,8 @@ def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=32, help="distinct rendered frames (tiled to --batch)")
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")

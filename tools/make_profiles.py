@@ -3,7 +3,7 @@
 
 Inputs (produced on the GPU box, see DESIGN.md section 5 for the commands):
   gpurun_out/bench_final.log            python bench.py                               (last line = the JSON)
-  gpurun_out/prof_f/f_kernel_stats.csv  rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+  gpurun_out/prof_f/f_kernel_stats.csv  rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline
   gpurun_out/pmc_{fetch,write,sq1,sq2}.csv   tools/pmc_summary.py over rocprofv3 --pmc passes of
                                         python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline
 usage: make_profiles.py <round tag, e.g. r01>"""
@@ -42,8 +42,8 @@ json.dump(bench, open(os.path.join(P, tag + "_bench_default.json"), "w"))
 dst = os.path.join(P, tag + "_f_kernel_stats.csv")
 shutil.copy(os.path.join(G, "prof_f", "f_kernel_stats.csv"), dst)
 body = open(dst).read()
-open(dst, "w").write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   (B=%d, pipeline 2; 10 launches "
-                     "per kernel = 2 set-up + 2 warm-up + 5 timed + 1 isolated; only warm-up/timed launches overlap with the other workspace)\n" % B + body)
+open(dst, "w").write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (B=%d, pipeline 2, 20 steps + 5 warm-up; 28 launches "
+                     "per kernel = 2 set-up + 5 warm-up + 20 timed + 1 isolated; only warm-up/timed launches overlap with the other workspace)\n" % B + body)
 
 _, f = table(os.path.join(G, "pmc_fetch.csv"))
 _, w = table(os.path.join(G, "pmc_write.csv"))
