@@ -92,7 +92,7 @@ def _bilinear(tex, u, v):
 
 
 def render_frame(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), cam_rotation_deg=(0, 0, 0),
-                 fov_y_deg=45.0, family="tagStandard41h12", cell_px=40, noise_sigma=0.0, rng=None):
+                 fov_y_deg=45.0, family="tagStandard41h12", cell_px=40, noise_sigma=0.0, rng=None, textures=None):
     """Render one H x W x 3 BGR uint8 frame.
 
     tags: iterable of dicts {"id", "position" [x,y,z], "rotation" [pitch,yaw,roll] deg} (the
@@ -135,7 +135,7 @@ def render_frame(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), ca
         inside = (X >= -half) & (X <= half) & (Y >= -half) & (Y <= half)
         if not inside.any():
             continue
-        tex = fam.texture(int(tag["id"]), cell_px)
+        tex = textures[int(tag["id"])] if textures is not None else fam.texture(int(tag["id"]), cell_px)
         th, tw = tex.shape[:2]
         u = (X + half) / (2 * half) * tw
         v = (1.0 - (Y + half) / (2 * half)) * th  # image row 0 is the top (t = 1)

@@ -421,8 +421,20 @@ static int fit_quad(const uint8_t *im, int w, int h, const aso_point *pts, int s
     double lines[4][4];
     if (!quad_segment_maxima(lfps, sz, indices)) goto finish;
     for (int i = 0; i < 4; i++) {
+        /* The points next to a corner are the least reliable ones of a side (a missing corner pixel or
+           unequal gradient weights on the two sides move the error maximum by a point or two), so a sixth
+           of the side is left out at either end -- the block upstream carries for this.  The reference's
+           committed run only reproduces with it on: see tests/golden/README.md. */
+        int i0 = indices[i], i1 = indices[(i + 1) & 3];
+        int len = i1 - i0;
+        if (len < 0) len += sz;
+        if (len > 8) {
+            int t = len / 6;
+            i0 = (i0 + t) % sz;
+            i1 = (i1 + sz - t) % sz;
+        }
         double mse;
-        fit_line(lfps, sz, indices[i], indices[(i + 1) & 3], lines[i], NULL, &mse);
+        fit_line(lfps, sz, i0, i1, lines[i], NULL, &mse);
         if (mse > MAX_LINE_FIT_MSE) goto finish;
     }
     for (int i = 0; i < 4; i++) {
@@ -512,6 +524,8 @@ static void half_angle_normal(double a /*Cyy-Cxx*/, double b /*-2Cxy*/, double *
     }
 }
 
+#define PIX_EPS 9.5367431640625e-07 /* 2^-20 px */
+
 void aso_refine_edges(const uint8_t *gray, int w, int h, int stride, int decimate, aso_quad *quad)
 {
     double lines[4][4];
@@ -535,9 +549,11 @@ void aso_refine_edges(const uint8_t *gray, int w, int h, int stride, int decimat
             for (int k = 0; k < steps; k++) {
                 double n = -range + 0.25 * k;
                 double grange = 1;
-                int x1 = (int)(x0 + (n + grange) * nx), y1 = (int)(y0 + (n + grange) * ny);
+                /* PIX_EPS: a probe that lands on a pixel boundary to within rounding error reads the
+                   pixel above it.  Edges that are exactly pixel-aligned put every fourth probe there. */
+                int x1 = (int)(x0 + (n + grange) * nx + PIX_EPS), y1 = (int)(y0 + (n + grange) * ny + PIX_EPS);
                 if (x1 < 0 || x1 >= w || y1 < 0 || y1 >= h) continue;
-                int x2 = (int)(x0 + (n - grange) * nx), y2 = (int)(y0 + (n - grange) * ny);
+                int x2 = (int)(x0 + (n - grange) * nx + PIX_EPS), y2 = (int)(y0 + (n - grange) * ny + PIX_EPS);
                 if (x2 < 0 || x2 >= w || y2 < 0 || y2 >= h) continue;
                 int g1 = gray[(size_t)y1 * stride + x1], g2 = gray[(size_t)y2 * stride + x2];
                 if (g1 < g2) continue;

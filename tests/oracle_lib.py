@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("ASO_SO") or os.path.join(ROOT, "oracle", "liboracle.so")  # ASO_SO: variant builds for diagnosis
 
 
 class AsoDetection(C.Structure):

@@ -7,6 +7,7 @@ held to 1e-9 px absolute (observed: identical)."""
 import numpy as np
 import pytest
 
+import golden_scene as G
 import oracle_lib as O
 from aprilslam_amd import synth
 
@@ -255,3 +256,24 @@ def test_adversarial_textures_grow_buffers_and_stay_in_parity(family):
         assert c[11] == 0 and c[12] == 0 and c[13] == 0 and c[14] == 0  # the accepted run had no overflow left
     finally:
         det.close()
+
+
+def test_reference_trajectory_on_gpu(gpu_detector, family):
+    """The reference's committed run (tests/golden/reference_trajectory.json: 60 pixel-aligned views of the default
+    scene, rendered with the reference's own tag images) through the HIP detector + PnP and the graph: stage parity
+    against the oracle on the knife-edge frames, and the reference's own logged camera pose as the known answer."""
+    rows = G.TRAJ[:G.N_TAG0_ROWS]
+    frames = np.stack([G.render(G.camera_position(r))[0] for r in rows])
+    check_stages(gpu_detector, frames[[0, 7, 15, 33, 35]], family)
+    dets, npf = gpu_detector.detect_host(frames)
+    rv, tv, T, ok = gpu_detector.solve_pnp(dets["corners"], G.K, np.zeros(4), G.TAG_SIZE)
+    assert ok.all()
+    slam = G.new_slam()
+    start, d_ref = 0, []
+    for b, row in enumerate(rows):
+        sl = slice(start, start + npf[b])
+        start += npf[b]
+        pose = G.feed(slam, [int(i) for i in dets["id"][sl]], T[sl])
+        d_ref.append(np.linalg.norm(pose[:3, 3] - np.array(row["est_xyz"])))
+    d_ref = np.array(d_ref)
+    assert d_ref[0] < 0.02 and d_ref[:31].max() < 0.03 and (d_ref < 0.05).sum() >= 42 and (d_ref < 0.25).all(), np.round(d_ref, 3)
