@@ -36,7 +36,7 @@ assert POSE_DTYPE.itemsize == C.sizeof(AslPose)
 assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
-    "asl_detector_create", "asl_detector_destroy", "asl_last_error", "asl_version", "asl_detect_gray_u8",
+    "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_last_error", "asl_version", "asl_detect_gray_u8",
     "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
@@ -66,6 +66,7 @@ def load():
     L.asl_detector_create.argtypes = [C.c_char_p, i32, i32, C.c_float, C.c_float, i32, i32, C.POINTER(vp)]
     L.asl_detector_destroy.argtypes = [vp]
     L.asl_detector_destroy.restype = None
+    L.asl_detector_set_id_limit.argtypes = [vp, i32]
     L.asl_detect_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_bgr_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_batch_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -95,13 +96,16 @@ class Detector:
     """Owns one asl_detector (one GPU workspace).  Not re-entrant."""
 
     def __init__(self, family="tagStandard41h12", threads=1, maxhamming=1, decimate=2.0, blur=0.0, refine_edges=True,
-                 device=0):
+                 device=0, id_limit=None):
+        """id_limit: None = the ids the reference pins (0..4); 0 = the whole (build-defined) table; n = ids 0..n-1."""
         L = load()
         self._L = L
         self._h = C.c_void_p()
         check(L.asl_detector_create(family.encode(), int(threads), int(maxhamming), float(decimate), float(blur),
                                     1 if refine_edges else 0, int(device), C.byref(self._h)))
         self.device = int(device)
+        if id_limit is not None:
+            check(L.asl_detector_set_id_limit(self._h, int(id_limit)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -16,11 +16,12 @@ from . import _lib
 
 class apriltag(object):
     def __init__(self, family, threads=1, maxhamming=1, decimate=2.0, blur=0.0, refine_edges=True, debug=False,
-                 device=0):
+                 device=0, id_limit=None):
         if not isinstance(family, str):
             raise TypeError("family must be a string")
         try:
-            self._det = _lib.Detector(family, threads, maxhamming, decimate, blur, refine_edges, device)
+            # id_limit=None: only the ids the reference pins (0..4) are decoded; 0 opens the build-defined rest
+            self._det = _lib.Detector(family, threads, maxhamming, decimate, blur, refine_edges, device, id_limit)
         except _lib.AslError as e:
             # upstream raises RuntimeError for an unrecognised family / bad options
             raise RuntimeError(str(e))

@@ -135,7 +135,7 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
     d->fam.width_at_border = kTag41h12WidthAtBorder;
     d->fam.total_width = kTag41h12TotalWidth;
     d->fam.reversed_border = 1;
-    d->fam.ncodes = kTag41h12NCodes;
+    d->fam.ncodes = kTag41h12PinnedIds;  // ids the reference's own tag images pin; asl_detector_set_id_limit opens the rest
     for (int i = 0; i < kTag41h12NBits; i++) { d->fam.bit_x[i] = kTag41h12BitX[i]; d->fam.bit_y[i] = kTag41h12BitY[i]; }
     if (hipMalloc((void **)&d->d_codes, sizeof(unsigned long long) * kTag41h12NCodes) != hipSuccess) {
         delete d;
@@ -157,6 +157,8 @@ extern "C" void asl_detector_destroy(asl_detector *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
+    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release();
     d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
@@ -167,6 +169,15 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
     for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
     delete d;
+}
+
+extern "C" int asl_detector_set_id_limit(asl_detector *d, int n_ids)
+{
+    if (!d) return fail(ASL_EINVAL, "detector is NULL");
+    if (n_ids > kTag41h12NCodes) return fail(ASL_EINVAL, "the code table holds %d ids (asked for %d)", kTag41h12NCodes, n_ids);
+    if (d->pending) return fail(ASL_EINVAL, "a batch is in flight on this detector");
+    d->fam.ncodes = n_ids <= 0 ? kTag41h12NCodes : n_ids;
+    return ASL_OK;
 }
 
 extern "C" int asl_set_profiling(asl_detector *d, int enabled)

@@ -28,8 +28,8 @@ def rodrigues(rvec):
 class TagDetector:
     """Handles AprilTag detection and pose estimation (GPU-backed)."""
 
-    def __init__(self, camera_params, tag_type="tagStandard41h12", tag_size=0.06, device=0):
-        self.detector = apriltag(tag_type, device=device)
+    def __init__(self, camera_params, tag_type="tagStandard41h12", tag_size=0.06, device=0, id_limit=None):
+        self.detector = apriltag(tag_type, device=device, id_limit=id_limit)
         self.tag_size = tag_size
         self.camera_matrix = camera_params['camera_matrix']
         self.dist_coeffs = camera_params['dist_coeffs']

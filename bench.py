@@ -179,7 +179,7 @@ def main():
     # post-processing (dedup/sort/copy-out) and the latency-bound tail kernels of one batch overlap the bulk
     # kernels of the next.  P = 1 is the plain synchronous call.
     P = max(1, args.pipeline)
-    detectors = [_lib.Detector("tagStandard41h12", device=local_rank) for _ in range(P)]
+    detectors = [_lib.Detector("tagStandard41h12", device=local_rank, id_limit=0) for _ in range(P)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
     for dd in detectors:
         dd.set_profiling(True)

@@ -68,6 +68,12 @@ typedef struct {
 int asl_detector_create(const char *family, int nthreads, int maxhamming, float decimate, float blur,
                         int refine_edges, int device, asl_detector **out);
 void asl_detector_destroy(asl_detector *det);
+/* Which ids the decoder may return.  Only ids 0..4 of tagStandard41h12 are pinned by the reference (its
+   assets/tags/tag{0..4}.png); upstream's 2115-entry code table is not in the reference tree, so the other
+   entries of this library's table are build-defined and would mislabel a physical tag with id >= 5.  A new
+   detector therefore decodes ids 0..4 only.  n_ids <= 0 opens the whole table (synthetic scenes rendered from
+   the same table), n_ids > 0 keeps ids 0..n_ids-1. */
+int asl_detector_set_id_limit(asl_detector *det, int n_ids);
 const char *asl_last_error(void);
 /* "aprilslam <version> gfx950 ..." */
 const char *asl_version(void);

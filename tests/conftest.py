@@ -23,6 +23,6 @@ def family():
 def gpu_detector():
     """One HIP detector for the whole GPU session (fails loudly if the library or GPU is missing)."""
     from aprilslam_amd import _lib
-    det = _lib.Detector("tagStandard41h12")
+    det = _lib.Detector("tagStandard41h12", id_limit=0)
     yield det
     det.close()

@@ -128,7 +128,7 @@ def test_tag_detector_detect_carries_the_pose_get_pose_would_compute(family):
     frame, _ = scene_frame(1280, 720, 20, 11)
     K = synth.camera_matrix(1280, 720)
     for dist in (np.zeros((4, 1)), np.array([0.05, -0.02, 0.001, -0.0005, 0.01])):
-        td = TagDetector({"camera_matrix": K, "dist_coeffs": dist}, tag_size=10.0)
+        td = TagDetector({"camera_matrix": K, "dist_coeffs": dist}, tag_size=10.0, id_limit=0)
         dets = td.detect(frame)
         assert len(dets) == 20
         for d in dets:
@@ -140,6 +140,46 @@ def test_tag_detector_detect_carries_the_pose_get_pose_would_compute(family):
         e = dict(dets[0]); e["lb-rb-rt-lt"] = dets[0]["lb-rb-rt-lt"] + 1.0
         assert not np.array_equal(td.get_pose(e)[2], td.get_pose(dets[0])[2])
         td.detector._det.close()
+
+
+def test_only_reference_pinned_ids_by_default(family):
+    """A detector decodes ids 0..4 (the ones the reference's tag images pin) unless the build-defined rest of the
+    table is opened; the oracle with a 5-entry code book gives the same detections."""
+    import copy
+    from aprilslam_amd import _lib
+    frame, _ = scene_frame(1280, 720, 20, 11)
+    det = _lib.Detector("tagStandard41h12")
+    dets, _ = det.detect_host(frame)
+    fam5 = copy.copy(family)
+    fam5.codes = family.codes[:family.pinned_ids]
+    ref = O.detect_bgr(frame, fam5)
+    assert family.pinned_ids == 5 and sorted(int(d["id"]) for d in dets) == [0, 1, 2, 3, 4]
+    assert [int(d["id"]) for d in dets] == [r["id"] for r in ref]
+    for d, r in zip(dets, ref):
+        assert np.abs(d["corners"] - r["corners"]).max() <= CORNER_TOL
+    with pytest.raises(_lib.AslError):
+        _lib.check(det._L.asl_detector_set_id_limit(det._h, 100000))
+    det.close()
+
+
+def test_host_rodrigues_matches_device_T(gpu_detector):
+    """TagDetector.transformation (host Rodrigues, tag_detector.py:45-52) against the T the PnP kernel returns,
+    and the Euler / distance helpers against their closed forms."""
+    from aprilslam_amd.tag_detector import TagDetector, rodrigues
+    frame, _ = scene_frame(1280, 720, 20, 11)
+    dets, _ = gpu_detector.detect_host(frame)
+    K = synth.camera_matrix(1280, 720)
+    rv, tv, T, ok = gpu_detector.solve_pnp(dets["corners"], K, np.zeros(4), 10.0)
+    td = TagDetector.__new__(TagDetector)
+    for r, t, Td in zip(rv, tv, T):
+        Th = td.transformation(r.reshape(3, 1), t.reshape(3, 1))
+        assert np.abs(Th - Td).max() < 1e-12
+        assert abs(td.distance(t) - np.sqrt((t ** 2).sum())) < 1e-15
+    assert np.array_equal(rodrigues(np.zeros(3)), np.eye(3))
+    # yaw about y, pitch about x, roll about z for a pure rotation about one axis
+    for axis, idx in ((np.array([0, 1.0, 0]), 0), (np.array([0, 0, 1.0]), 2)):
+        e = td.euler_angles(0.3 * axis)
+        assert abs(e[idx] - np.degrees(0.3)) < 1e-9 and np.abs(np.delete(e, idx)).max() < 1e-9
 
 
 def test_errors_are_loud(gpu_detector):
@@ -190,7 +230,7 @@ def test_decimate_1_and_maxhamming_variants(family):
     from aprilslam_amd import _lib
     frame, _ = scene_frame(640, 480, 6, 31, noise=2.0)
     for dec, mh, refine in ((1, 1, True), (2, 0, True), (2, 2, False), (3, 1, True)):
-        det = _lib.Detector("tagStandard41h12", decimate=float(dec), maxhamming=mh, refine_edges=refine)
+        det = _lib.Detector("tagStandard41h12", decimate=float(dec), maxhamming=mh, refine_edges=refine, id_limit=0)
         try:
             dets, _ = det.detect_host(frame)
             gray = O.bgr2gray(frame)
@@ -211,7 +251,7 @@ def test_submit_collect_pipeline_equals_blocking_call(family):
     K = synth.camera_matrix(640, 360)
     batches = [np.stack([scene_frame(640, 360, 5, 300 + 10 * b + i)[0] for i in range(4)]) for b in range(3)]
     dev = [torch.from_numpy(b).to("cuda:0") for b in batches]
-    a, b2 = _lib.Detector(), _lib.Detector()
+    a, b2 = _lib.Detector(id_limit=0), _lib.Detector(id_limit=0)
     try:
         ref = [a.detect_device(t.data_ptr(), 4, 3, 640, 360, K=K, dist=np.zeros(4), tag_size=10.0) for t in dev]
         ref = [(r[0].copy(), r[1].copy(), r[2].copy()) for r in ref]
@@ -249,7 +289,7 @@ def test_adversarial_textures_grow_buffers_and_stay_in_parity(family):
     # in its small buffer, so these tiles go through the dense-tile launch
     stripes = ((((yy // 2) & 1) * 255)).astype(np.uint8)
     frames = np.stack([noise, checker, tagf, stripes])
-    det = _lib.Detector("tagStandard41h12")
+    det = _lib.Detector("tagStandard41h12", id_limit=0)
     try:
         dets, npf = check_stages(det, frames, family)
         c = det.debug_counters()

@@ -15,7 +15,7 @@ from aprilslam_amd import _lib, synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 frames = bench.make_frames(16)
 t = torch.from_numpy(frames).to("cuda:0").repeat((B + 15) // 16, 1, 1, 1)[:B].contiguous()
-det = _lib.Detector()
+det = _lib.Detector(id_limit=0)
 det.set_profiling(True)
 K = synth.camera_matrix(bench.W, bench.H)
 for it in range(3):

@@ -57,7 +57,7 @@ def main():
     tag_gt0 = np.array([G0i @ T for T in tag_gt])
     cam_gt0 = np.array([G0i @ T for T in cam_gt])
 
-    det = _lib.Detector()
+    det = _lib.Detector(id_limit=0)
     d_frames = torch.from_numpy(frames).to("cuda:0")
     det.detect_device(d_frames.data_ptr(), P, 3, W, H, K=K, dist=np.zeros(4), tag_size=10.0)  # warm-up / allocation
     torch.cuda.synchronize()
