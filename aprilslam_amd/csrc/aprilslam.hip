@@ -18,6 +18,7 @@
 #include "k_threshold.inc"
 #include "k_cc.inc"
 #include "k_cluster.inc"
+#include "k_seg.inc"
 #include "k_quad.inc"
 #include "k_decode.inc"
 #include "k_pnp.inc"
@@ -59,9 +60,11 @@ struct asl_detector {
     double points_per_pixel = 0.5;
 
     // workspace
-    DevBuf<uint8_t> in, dgray, thresh, tmin, tmax;
+    DevBuf<uint8_t> in, dgray, tmin, tmax;
+    DevBuf<uint8_t> dbg_thresh;         // asl_debug_fetch only: the threshold image as bytes
+    DevBuf<unsigned int> dbg_labels;    // asl_debug_fetch only: per-pixel labels
     DevBuf<unsigned int> parent, sizes;
-    DevBuf<unsigned long long> hkeys, points, rootmask;
+    DevBuf<unsigned long long> hkeys, points, rootmask, wmask, bmask;
     DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, quad_list;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
@@ -158,8 +161,9 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
-    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release();
-    d->in.release(); d->dgray.release(); d->thresh.release(); d->tmin.release(); d->tmax.release();
+    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->wmask.release(); d->bmask.release();
+    d->dbg_thresh.release(); d->dbg_labels.release();
+    d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
@@ -234,7 +238,9 @@ static int make_geom(asl_detector *d, int n_frames, int channels, int w, int h, 
     return ASL_OK;
 }
 
-static size_t count_tiles(const Geom &g) { return (size_t)((g.sw + CNT_TW - 1) / CNT_TW) * (size_t)((g.sh + CNT_TH - 1) / CNT_TH); }
+static int seg_nwx(const Geom &g) { return (g.sw + 63) / 64; }                       // 64-pixel words per row
+static int seg_point_tiles_y(const Geom &g) { return std::max(1, (g.sh - 1 + SEG_PH - 1) / SEG_PH); }  // k_seg_points tiles: rows 63k .. 63k+62 emit
+static size_t count_tiles(const Geom &g) { return (size_t)seg_nwx(g) * (size_t)seg_point_tiles_y(g); }
 
 static int ensure_workspace(asl_detector *d, const Geom &g)
 {
@@ -248,12 +254,13 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     d->max_dets = (unsigned int)std::min<unsigned long long>((unsigned long long)B * d->dets_per_frame, 0x7FFFFFFFull);
     int bad = 0;
     bad |= d->dgray.ensure(total);
-    bad |= d->thresh.ensure(total);
     bad |= d->tmin.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->parent.ensure(total);
     bad |= d->sizes.ensure(total);
-    bad |= d->rootmask.ensure(B * (size_t)g.sh * (size_t)((g.sw + CCT_W - 1) / CCT_W));
+    bad |= d->rootmask.ensure(B * (size_t)g.sh * (size_t)seg_nwx(g));
+    bad |= d->wmask.ensure(B * (size_t)g.sh * (size_t)seg_nwx(g));
+    bad |= d->bmask.ensure(B * (size_t)g.sh * (size_t)seg_nwx(g));
     bad |= d->hkeys.ensure(d->nslots);
     bad |= d->hcounts.ensure(d->nslots);
     bad |= d->class_lists.ensure((size_t)NCLASSES * d->max_clusters);
@@ -298,30 +305,27 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_decimate_minmax");
     hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((g.sw + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
 
-    STAGE("k_cc_tile");
-    dim3 cgrid((g.sw + CCT_W - 1) / CCT_W, (g.sh + CCT_H - 1) / CCT_H, B);
-    hipLaunchKernelGGL(k_cc_tile, cgrid, dim3(256), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, d->thresh.p, d->parent.p, d->sizes.p,
-                       d->rootmask.p);
-    STAGE("k_cc_border");
-    hipLaunchKernelGGL(k_cc_border, dim3((cgrid.x + 1) / 2, cgrid.y, cgrid.z), dim3(256), 0, st, d->thresh.p, g, d->parent.p);
-    STAGE("k_cc_roots");
-    {
-        size_t words = (size_t)B * g.sh * cgrid.x;
-        hipLaunchKernelGGL(k_cc_roots, dim3((unsigned int)((words + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, (int)cgrid.x,
-                           d->parent.p, d->sizes.p);
-    }
+    const int nwx = seg_nwx(g), pty = seg_point_tiles_y(g);
+    const size_t nwords = (size_t)B * g.sh * nwx;
+    STAGE("k_seg_tile");
+    hipLaunchKernelGGL(k_seg_tile, dim3(nwx, (g.sh + SEG_TH - 1) / SEG_TH, B), dim3(64), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, nwx,
+                       d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
+    STAGE("k_seg_border");
+    hipLaunchKernelGGL(k_seg_border, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+                       d->counters.p);
+    STAGE("k_seg_roots");
+    hipLaunchKernelGGL(k_seg_roots, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, nwx, d->parent.p, d->sizes.p);
 
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
-    STAGE("k_cluster_count");
-    dim3 tgrid(B, (g.sw + CNT_TW - 1) / CNT_TW, (g.sh + CNT_TH - 1) / CNT_TH);  // workgroup = 64x16 pixel tile, frame-major
-    hipLaunchKernelGGL((k_cluster_count<CNT_TW * CNT_TH, false>), tgrid, blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p,
-                       d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->dense_tiles.p,
-                       (int)tgrid.y, (int)tgrid.z, d->counters.p);
-    // tiles too dense for the small parking buffer (none in ordinary frames: the launch finds an empty list)
-    hipLaunchKernelGGL((k_cluster_count<4 * CNT_TW * CNT_TH, true>), dim3(256), blk, 0, st, d->thresh.p, g, d->parent.p, d->sizes.p, d->hkeys.p,
-                       d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->dense_tiles.p,
-                       (int)tgrid.y, (int)tgrid.z, d->counters.p);
+    STAGE("k_seg_points");
+    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP, SEGP_RUNCAP, 1>), dim3(B, nwx, pty), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+                       d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
+                       d->dense_tiles.p, pty, d->counters.p);
+    // tiles with more runs or points than the common launch stages (none in ordinary frames: the launch finds an empty list)
+    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP_DENSE, SEGP_RUNCAP_DENSE, 2>), dim3(256), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+                       d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
+                       d->dense_tiles.p, pty, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");
@@ -525,6 +529,10 @@ static int collect_batch(asl_detector *d, asl_detection *out, asl_pose *poses, i
         memcpy(d->last_counters, d->pinned_counters, sizeof(long long) * CNT__N);
         d->last = g;
         long long *c = d->last_counters;
+        if (c[CNT_UF_GUARD]) {
+            d->pending = false;
+            return fail(ASL_ECAPACITY, "a union-find loop hit its iteration guard (%lld times): labels of this batch are not trustworthy", c[CNT_UF_GUARD]);
+        }
         bool again = false;
         if (c[CNT_OVERFLOW_HASH]) { d->hash_slots_per_frame *= 4; again = true; }
         if (c[CNT_OVERFLOW_CLUSTERS] || c[CNT_NCLUSTERS] > (long long)d->max_clusters) { d->clusters_per_frame *= 4; again = true; }
@@ -726,29 +734,44 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
     size_t total = (size_t)g.nframes * g.npix;
     if (what >= 0 && what <= 3 && total == 0) return fail(ASL_EINVAL, "no batch has run yet");
     switch (what) {
-    case 0:
-    case 1: {
+    case 0: {
         if (bytes < total) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total);
-        HIPCHK(hipMemcpy(dst, what == 0 ? d->dgray.p : d->thresh.p, total, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(dst, d->dgray.p, total, hipMemcpyDeviceToHost));
         *n_items = total;
         return ASL_OK;
     }
-    case 2:
-    case 3: {
+    case 1: {  // the pipeline keeps the threshold image as two bit masks per 64 pixels: expand it for the caller
+        if (bytes < total) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total);
+        if (d->dbg_thresh.ensure(total)) return fail(ASL_ENOMEM, "debug buffer allocation failed");
+        hipLaunchKernelGGL(k_seg_debug_thresh, dim3((g.sw + 63) / 64, (g.sh + 3) / 4, (unsigned int)g.nframes), dim3(64, 4), 0, nullptr,
+                           d->wmask.p, d->bmask.p, g, seg_nwx(g), d->dbg_thresh.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(dst, d->dbg_thresh.p, total, hipMemcpyDeviceToHost));
+        *n_items = total;
+        return ASL_OK;
+    }
+    case 2: {  // labels live at run starts (run start -> tile-local root -> global root): resolve them per pixel for the caller
         if (bytes < total * 4) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total * 4);
-        if (what == 2) {  // the pipeline keeps two-level labels (pixel -> tile root -> global root): flatten them for the caller
-            hipLaunchKernelGGL(k_cc_flatten, dim3((g.sw + 63) / 64, (g.sh + 3) / 4, (unsigned int)g.nframes), dim3(64, 4), 0, nullptr,
-                               d->thresh.p, g, d->parent.p);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipMemcpy(dst, what == 2 ? d->parent.p : d->sizes.p, total * 4, hipMemcpyDeviceToHost));
-        {   // labels/sizes of 127 pixels are implied, not stored: fill them in for the caller
-            std::vector<uint8_t> th(total);
-            HIPCHK(hipMemcpy(th.data(), d->thresh.p, total, hipMemcpyDeviceToHost));
-            unsigned int *o = (unsigned int *)dst;
-            for (size_t i = 0; i < total; i++)
-                if (th[i] == 127) o[i] = what == 2 ? (unsigned int)(i % g.npix) : 1u;
-        }
+        if (d->dbg_labels.ensure(total)) return fail(ASL_ENOMEM, "debug buffer allocation failed");
+        hipLaunchKernelGGL(k_seg_debug_labels, dim3((g.sw + 63) / 64, (g.sh + 3) / 4, (unsigned int)g.nframes), dim3(64, 4), 0, nullptr,
+                           d->wmask.p, d->bmask.p, g, seg_nwx(g), d->parent.p, d->dbg_labels.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(dst, d->dbg_labels.p, total * 4, hipMemcpyDeviceToHost));
+        *n_items = total;
+        return ASL_OK;
+    }
+    case 3: {  // sizes are kept at the global roots; "no contrast" pixels are singletons whose size is implied
+        if (bytes < total * 4) return fail(ASL_EINVAL, "dst too small: need %zu bytes", total * 4);
+        if (d->dbg_thresh.ensure(total)) return fail(ASL_ENOMEM, "debug buffer allocation failed");
+        hipLaunchKernelGGL(k_seg_debug_thresh, dim3((g.sw + 63) / 64, (g.sh + 3) / 4, (unsigned int)g.nframes), dim3(64, 4), 0, nullptr,
+                           d->wmask.p, d->bmask.p, g, seg_nwx(g), d->dbg_thresh.p);
+        HIPCHK(hipGetLastError());
+        std::vector<uint8_t> th(total);
+        HIPCHK(hipMemcpy(th.data(), d->dbg_thresh.p, total, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(dst, d->sizes.p, total * 4, hipMemcpyDeviceToHost));
+        unsigned int *o = (unsigned int *)dst;
+        for (size_t i = 0; i < total; i++)
+            if (th[i] == 127) o[i] = 1u;
         *n_items = total;
         return ASL_OK;
     }

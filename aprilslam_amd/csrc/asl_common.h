@@ -104,6 +104,7 @@ enum {
     CNT_CLASS3,
     CNT_CLASS4,
     CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
+    CNT_UF_GUARD,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
     CNT__N = 16
 };
 
