@@ -60,7 +60,7 @@ struct asl_detector {
     double points_per_pixel = 0.5;
 
     // workspace
-    DevBuf<uint8_t> in, dgray, tmin, tmax;
+    DevBuf<uint8_t> in, dgray, tmin, tmax, tcut;
     DevBuf<uint8_t> dbg_thresh;         // asl_debug_fetch only: the threshold image as bytes
     DevBuf<unsigned int> dbg_labels;    // asl_debug_fetch only: per-pixel labels
     DevBuf<unsigned int> parent, sizes;
@@ -163,7 +163,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
     d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->wmask.release(); d->bmask.release();
     d->dbg_thresh.release(); d->dbg_labels.release();
-    d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release();
+    d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release(); d->tcut.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
@@ -256,6 +256,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->dgray.ensure(total);
     bad |= d->tmin.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th));
+    bad |= d->tcut.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->parent.ensure(total);
     bad |= d->sizes.ensure(total);
     bad |= d->rootmask.ensure(B * (size_t)g.sh * (size_t)seg_nwx(g));
@@ -307,25 +308,34 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
 
     const int nwx = seg_nwx(g), pty = seg_point_tiles_y(g);
     const size_t nwords = (size_t)B * g.sh * nwx;
+    STAGE("k_tile_cut");
+    if (g.tw > 0 && g.th > 0)
+        hipLaunchKernelGGL(k_tile_cut, dim3((g.tw + 63) / 64, (g.th + 3) / 4, B), dim3(64, 4), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
     STAGE("k_seg_tile");
-    hipLaunchKernelGGL(k_seg_tile, dim3(nwx, (g.sh + SEG_TH - 1) / SEG_TH, B), dim3(64), 0, st, d->dgray.p, d->tmin.p, d->tmax.p, g, nwx,
+    hipLaunchKernelGGL(k_seg_tile, dim3(nwx, (g.sh + SEG_TH - 1) / SEG_TH, B), dim3(64), 0, st, d->dgray.p, d->tcut.p, g, nwx,
                        d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
     STAGE("k_seg_border");
-    hipLaunchKernelGGL(k_seg_border, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
-                       d->counters.p);
+    if (nwx > 1) {
+        const size_t nseams = (size_t)B * g.sh * (nwx - 1);
+        hipLaunchKernelGGL(k_seg_border_cols, dim3((unsigned int)((nseams + 255) / 256)), dim3(256), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+                           d->counters.p);
+    }
+    if ((g.sh - 1) / SEG_TH > 0)
+        hipLaunchKernelGGL(k_seg_border_rows, dim3(nwx, (g.sh - 1) / SEG_TH, B), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+                           d->counters.p);
     STAGE("k_seg_roots");
     hipLaunchKernelGGL(k_seg_roots, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, nwx, d->parent.p, d->sizes.p);
 
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_seg_points");
-    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP, SEGP_RUNCAP, 1>), dim3(B, nwx, pty), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
-                       d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
-                       d->dense_tiles.p, pty, d->counters.p);
-    // tiles with more runs or points than the common launch stages (none in ordinary frames: the launch finds an empty list)
-    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP_DENSE, SEGP_RUNCAP_DENSE, 2>), dim3(256), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
-                       d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
-                       d->dense_tiles.p, pty, d->counters.p);
+    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP, SEGP_RUNCAP, SEGP_NW, 1>), dim3(B, (nwx + SEGP_NW - 1) / SEGP_NW, pty), dim3(64 * SEGP_NW), 0, st,
+                       d->wmask.p, d->bmask.p, g, nwx, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p,
+                       d->stage_pos.p, d->frame_cursor.p, d->stage_cap, d->dense_tiles.p, pty, d->counters.p);
+    // tiles of workgroups that ran out of staging space (none in ordinary frames: the launch finds an empty list)
+    hipLaunchKernelGGL((k_seg_points<SEGP_PCAP_DENSE, SEGP_RUNCAP_DENSE, 1, 2>), dim3(256), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx,
+                       d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p,
+                       d->stage_cap, d->dense_tiles.p, pty, d->counters.p);
     int tag_width = d->fam.width_at_border / g.f;
     if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");
