@@ -304,7 +304,17 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
 
     STAGE("k_decimate_minmax");
-    hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((g.sw + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
+    if (g.f == 2) {
+        const unsigned int ntile = (unsigned int)(g.tw * g.th);
+        const unsigned int nrest = (unsigned int)(g.sw - 4 * g.tw) * (unsigned int)g.sh + (unsigned int)(g.sh - 4 * g.th) * (unsigned int)(4 * g.tw);
+        if (ntile)
+            hipLaunchKernelGGL((g.channels == 1 ? k_decimate2_tiles<1> : k_decimate2_tiles<3>), dim3((ntile + 255) / 256, B), dim3(256), 0, st, d_frames, g,
+                               d->dgray.p, d->tmin.p, d->tmax.p);
+        if (nrest)
+            hipLaunchKernelGGL((g.channels == 1 ? k_decimate_rest<1> : k_decimate_rest<3>), dim3((nrest + 255) / 256, B), dim3(256), 0, st, d_frames, g,
+                               d->dgray.p);
+    } else
+        hipLaunchKernelGGL((g.channels == 1 ? k_decimate_minmax<1> : k_decimate_minmax<3>), dim3((g.sw + 63) / 64, (thx + 3) / 4, B), blk, 0, st, d_frames, g, d->dgray.p, d->tmin.p, d->tmax.p);
 
     const int nwx = seg_nwx(g), pty = seg_point_tiles_y(g);
     const size_t nwords = (size_t)B * g.sh * nwx;
@@ -314,12 +324,13 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_seg_tile");
     hipLaunchKernelGGL(k_seg_tile, dim3(nwx, (g.sh + SEG_TH - 1) / SEG_TH, B), dim3(64), 0, st, d->dgray.p, d->tcut.p, g, nwx,
                        d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
-    STAGE("k_seg_border");
+    STAGE("k_seg_border_cols");
     if (nwx > 1) {
         const size_t nseams = (size_t)B * g.sh * (nwx - 1);
         hipLaunchKernelGGL(k_seg_border_cols, dim3((unsigned int)((nseams + 255) / 256)), dim3(256), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
                            d->counters.p);
     }
+    STAGE("k_seg_border_rows");
     if ((g.sh - 1) / SEG_TH > 0)
         hipLaunchKernelGGL(k_seg_border_rows, dim3(nwx, (g.sh - 1) / SEG_TH, B), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
                            d->counters.p);

@@ -281,7 +281,7 @@ def main():
                 roof["traffic_source"] = tr["source"]
         except Exception:
             pass
-        seg_names = ("memset", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border", "k_seg_roots",
+        seg_names = ("memset", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border_cols", "k_seg_border_rows", "k_seg_roots",
                                              "k_hash_clear", "k_seg_points", "k_cluster_filter", "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
