@@ -327,7 +327,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_seg_border_cols");
     if (nwx > 1) {
         const size_t nseams = (size_t)B * g.sh * (nwx - 1);
-        hipLaunchKernelGGL(k_seg_border_cols, dim3((unsigned int)((nseams + 255) / 256)), dim3(256), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
+        hipLaunchKernelGGL(k_seg_border_cols, dim3((unsigned int)((nseams + 63) / 64)), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
                            d->counters.p);
     }
     STAGE("k_seg_border_rows");
