@@ -151,7 +151,7 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
     }
     d->fam.codes = d->d_codes;
     // class-3 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS3_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * CLASS3_CAP);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS3_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, QUAD_LDS_BYTES(CLASS3_CAP));
     *out = d;
     return ASL_OK;
 }
@@ -363,19 +363,19 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
     unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
     STAGE("k_fit_quads<0>");
-    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), 64 * CLASS0_CAP, st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
+    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<1>");
     // two wavefronts per cluster here: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
-    hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), 64 * CLASS1_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), QUAD_LDS_BYTES(CLASS1_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<2>");
-    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), 64 * CLASS2_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS2_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<3>");
-    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), 64 * CLASS3_CAP, st, d->clusters.p,
+    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS3_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
     STAGE("k_fit_quads<4>");
