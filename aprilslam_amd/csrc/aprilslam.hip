@@ -22,6 +22,7 @@
 #include "k_quad.inc"
 #include "k_decode.inc"
 #include "k_pnp.inc"
+#include "k_dedup.inc"
 #include "k_gn.inc"
 
 static thread_local std::string g_err;
@@ -73,6 +74,10 @@ struct asl_detector {
     DevBuf<QuadRec> quads;
     DevBuf<double> scratch, quadH;
     DevBuf<DetRec> dets;
+    // S8 on the device: per-frame index lists, counts and offsets, and the results in the ABI's layout
+    DevBuf<unsigned int> frame_ndets, frame_idx, frame_nkeep, frame_off;
+    DevBuf<DetOut> out_det;
+    DevBuf<PoseOut> out_pose;
     DevBuf<long long> counters;
     DevBuf<float> pnp_corners;
     DevBuf<double> pnp_out;
@@ -93,8 +98,11 @@ struct asl_detector {
     size_t prefetched = 0, nd_guess = 0;
     std::chrono::steady_clock::time_point t_submit, t_enqueued;
     long long *pinned_counters = nullptr;  // D2H target that does not force a blocking staging copy
-    DetRec *host_dets = nullptr;  // pinned
-    size_t host_dets_cap = 0;
+    DetOut *host_det = nullptr;    // pinned staging of the results
+    PoseOut *host_pose = nullptr;
+    size_t host_cap = 0;
+    unsigned int *host_nkeep = nullptr;  // pinned, per frame
+    size_t host_nkeep_cap = 0;
 
     // profiling
     int profiling = 0;
@@ -163,13 +171,16 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
     d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->wmask.release(); d->bmask.release();
     d->dbg_thresh.release(); d->dbg_labels.release();
+    d->frame_ndets.release(); d->frame_idx.release(); d->frame_nkeep.release(); d->frame_off.release(); d->out_det.release(); d->out_pose.release();
+    if (d->host_pose) (void)hipHostFree(d->host_pose);
+    if (d->host_nkeep) (void)hipHostFree(d->host_nkeep);
     d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release(); d->tcut.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->d_codes) (void)hipFree(d->d_codes);
-    if (d->host_dets) (void)hipHostFree(d->host_dets);
+    if (d->host_det) (void)hipHostFree(d->host_det);
     if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
     for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
     delete d;
@@ -278,6 +289,12 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->dense_tiles.ensure(B * count_tiles(g));
     bad |= d->scratch.ensure((size_t)d->max_points * 8);
     bad |= d->dets.ensure(d->max_dets);
+    bad |= d->frame_ndets.ensure(B);
+    bad |= d->frame_nkeep.ensure(B);
+    bad |= d->frame_off.ensure(B);
+    bad |= d->frame_idx.ensure(B * (size_t)d->dets_per_frame);
+    bad |= d->out_det.ensure(d->max_dets);
+    bad |= d->out_pose.ensure(d->max_dets);
     bad |= d->counters.ensure(CNT__N);
     if (bad) return fail(ASL_ENOMEM, "device workspace allocation failed (%zu frames of %dx%d)", B, g.sw, g.sh);
     return ASL_OK;
@@ -302,6 +319,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("memset");
     HIPCHK(hipMemsetAsync(d->counters.p, 0, sizeof(long long) * CNT__N, st));
     HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
+    HIPCHK(hipMemsetAsync(d->frame_ndets.p, 0, sizeof(unsigned int) * B, st));
 
     STAGE("k_decimate_minmax");
     if (g.f == 2) {
@@ -399,6 +417,18 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
         const int lpw = pnp_lpw(d->nd_guess ? d->nd_guess : (size_t)20 * B);  // detections of the previous batch, else a guess
         hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + lpw - 1) / lpw), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam, lpw);
     }
+    // ---- S8: de-duplicate, order by id, lay out the results
+    STAGE("k_det_dedup");
+    {
+        const unsigned int cap_f = d->dets_per_frame;
+        hipLaunchKernelGGL(k_det_bucket, dim3((d->max_dets + 255) / 256), dim3(256), 0, st, d->dets.p, d->counters.p, d->max_dets, d->frame_ndets.p,
+                           d->frame_idx.p, cap_f, d->counters.p);
+        hipLaunchKernelGGL(k_det_dedup, dim3(B), dim3(256), 0, st, d->dets.p, d->counters.p, d->frame_ndets.p, d->frame_idx.p, cap_f,
+                           d->frame_nkeep.p, d->counters.p);
+        hipLaunchKernelGGL(k_det_offsets, dim3(1), dim3(1024), 0, st, d->frame_nkeep.p, B, d->frame_off.p, d->counters.p);
+        hipLaunchKernelGGL(k_det_gather, dim3((cap_f + 255) / 256, B), dim3(256), 0, st, d->dets.p, d->frame_idx.p, cap_f, d->frame_nkeep.p,
+                           d->frame_off.p, d->out_det.p, d->out_pose.p, d->max_dets, cam ? 1 : 0);
+    }
     if (d->profiling && d->nev <= MAX_STAGES) HIPCHK(hipEventRecord(d->ev[d->nev], st));
     HIPCHK(hipGetLastError());
     return ASL_OK;
@@ -415,92 +445,25 @@ static CamDev make_cam(const double *K, const double *dist, int n_dist, double t
     return c;
 }
 
-// ---- host-side S8: drop overlapping duplicates, sort by id (tag_detector.py:27 re-sorts by id anyway)
-static bool seg_intersect(const double *a, const double *b, const double *c, const double *dd)
-{
-    double d1 = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
-    double d2 = (b[0] - a[0]) * (dd[1] - a[1]) - (b[1] - a[1]) * (dd[0] - a[0]);
-    double d3 = (dd[0] - c[0]) * (a[1] - c[1]) - (dd[1] - c[1]) * (a[0] - c[0]);
-    double d4 = (dd[0] - c[0]) * (b[1] - c[1]) - (dd[1] - c[1]) * (b[0] - c[0]);
-    return ((d1 > 0) != (d2 > 0)) && ((d3 > 0) != (d4 > 0));
-}
-static bool point_in_quad(const double q[4][2], const double *p)
-{
-    int pos = 0, neg = 0;
-    for (int i = 0; i < 4; i++) {
-        const double *a = q[i], *b = q[(i + 1) & 3];
-        double c = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]);
-        if (c > 0) pos++; else if (c < 0) neg++;
-    }
-    return pos == 0 || neg == 0;
-}
-static bool quads_overlap(const double a[4][2], const double b[4][2])
-{
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++)
-            if (seg_intersect(a[i], a[(i + 1) & 3], b[j], b[(j + 1) & 3])) return true;
-    return point_in_quad(a, b[0]) || point_in_quad(b, a[0]);
-}
-static int prefer_smaller(int pref, double q0, double q1)
-{
-    if (pref) return pref;
-    if (q0 < q1) return -1;
-    if (q1 < q0) return 1;
-    return 0;
-}
-static bool det_less(const DetRec &a, const DetRec &b)
-{
-    if (a.frame != b.frame) return a.frame < b.frame;
-    if (a.id != b.id) return a.id < b.id;
-    if (a.hamming != b.hamming) return a.hamming < b.hamming;
-    for (int i = 0; i < 4; i++)
-        for (int k = 0; k < 2; k++)
-            if (a.corners[i][k] != b.corners[i][k]) return a.corners[i][k] < b.corners[i][k];
-    return false;
-}
-static bool det_key_less(const DetRec &a, const DetRec &b)
-{
-    if (a.frame != b.frame) return a.frame < b.frame;
-    return a.key < b.key;
-}
-
-// dedup one frame given as indices into hd (already in cluster-key order = the oracle's visiting
-// order); survivors are appended to `out` sorted by (id, hamming, corners)
-static void dedup_frame(const DetRec *hd, std::vector<unsigned int> &idx, std::vector<unsigned int> &out)
-{
-    int n = (int)idx.size();
-    for (int i0 = 0; i0 < n; i0++) {
-        for (int i1 = i0 + 1; i1 < n; i1++) {
-            const DetRec &a = hd[idx[i0]], &b = hd[idx[i1]];
-            if (a.id != b.id) continue;
-            if (!quads_overlap(a.corners, b.corners)) continue;
-            int pref = 0;
-            pref = prefer_smaller(pref, a.hamming, b.hamming);
-            pref = prefer_smaller(pref, -a.margin, -b.margin);
-            for (int i = 0; i < 4; i++) {
-                pref = prefer_smaller(pref, a.corners[i][0], b.corners[i][0]);
-                pref = prefer_smaller(pref, a.corners[i][1], b.corners[i][1]);
-            }
-            if (pref < 0) { idx.erase(idx.begin() + i1); n--; i1--; }
-            else { idx.erase(idx.begin() + i0); n--; i0--; break; }
-        }
-    }
-    std::sort(idx.begin(), idx.end(), [hd](unsigned int a, unsigned int b) { return det_less(hd[a], hd[b]); });
-    out.insert(out.end(), idx.begin(), idx.end());
-}
-
 using clk = std::chrono::steady_clock;
 static float msf(clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); }
 
-static int ensure_host_dets(asl_detector *d, size_t want)
+static int ensure_host_out(asl_detector *d, size_t want, size_t nframes)
 {
-    if (want <= d->host_dets_cap) return ASL_OK;
-    if (d->host_dets) (void)hipHostFree(d->host_dets);
-    d->host_dets = nullptr;
-    d->host_dets_cap = 0;
+    if (nframes > d->host_nkeep_cap) {
+        if (d->host_nkeep) (void)hipHostFree(d->host_nkeep);
+        d->host_nkeep = nullptr; d->host_nkeep_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&d->host_nkeep, nframes * sizeof(unsigned int), hipHostMallocDefault));
+        d->host_nkeep_cap = nframes;
+    }
+    if (want <= d->host_cap) return ASL_OK;
+    if (d->host_det) (void)hipHostFree(d->host_det);
+    if (d->host_pose) (void)hipHostFree(d->host_pose);
+    d->host_det = nullptr; d->host_pose = nullptr; d->host_cap = 0;
     want = std::max<size_t>(want * 2, 4096);
-    HIPCHK(hipHostMalloc((void **)&d->host_dets, want * sizeof(DetRec), hipHostMallocNonCoherent));  // coarse-grained: CPU-cached
-    d->host_dets_cap = want;
+    HIPCHK(hipHostMalloc((void **)&d->host_det, want * sizeof(DetOut), hipHostMallocNonCoherent));  // coarse-grained: CPU-cached
+    HIPCHK(hipHostMalloc((void **)&d->host_pose, want * sizeof(PoseOut), hipHostMallocNonCoherent));
+    d->host_cap = want;
     return ASL_OK;
 }
 
@@ -517,11 +480,13 @@ static int submit_batch(asl_detector *d, const uint8_t *d_frames, const Geom &g,
     if (!d->pinned_counters) HIPCHK(hipHostMalloc((void **)&d->pinned_counters, sizeof(long long) * CNT__N, hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(d->pinned_counters, d->counters.p, sizeof(long long) * CNT__N, hipMemcpyDeviceToHost, st));
     d->prefetched = 0;
-    if (d->nd_guess > 0) {
+    rc = ensure_host_out(d, std::min<size_t>(d->nd_guess, d->max_dets), (size_t)g.nframes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d->host_nkeep, d->frame_nkeep.p, sizeof(unsigned int) * (size_t)g.nframes, hipMemcpyDeviceToHost, st));
+    if (d->nd_guess > 0) {  // as many results as the previous batch produced: the usual case needs no second copy
         size_t guess = std::min<size_t>(d->nd_guess, d->max_dets);
-        rc = ensure_host_dets(d, guess);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(d->host_dets, d->dets.p, guess * sizeof(DetRec), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(d->host_det, d->out_det.p, guess * sizeof(DetOut), hipMemcpyDeviceToHost, st));
+        if (cam) HIPCHK(hipMemcpyAsync(d->host_pose, d->out_pose.p, guess * sizeof(PoseOut), hipMemcpyDeviceToHost, st));
         d->prefetched = guess;
     }
     d->pending = true;
@@ -574,57 +539,27 @@ static int collect_batch(asl_detector *d, asl_detection *out, asl_pose *poses, i
         d->nstages = d->nev;
         for (int i = 0; i < d->nev; i++) HIPCHK(hipEventElapsedTime(&d->stage_ms[i], d->ev[i], d->ev[i + 1]));
     }
-    size_t nd = (size_t)d->last_counters[CNT_NDETS];
+    if (d->last_counters[CNT_DEDUP_LIMIT])
+        return fail(ASL_ECAPACITY, "%lld frame(s) hold more than %d detections: the de-duplication does not sort that many", d->last_counters[CNT_DEDUP_LIMIT], DEDUP_MAX);
+    size_t nd = (size_t)d->last_counters[CNT_NKEEP];
+    if (nd > d->max_dets) nd = d->max_dets;
     if (nd > d->prefetched) {
         size_t have = d->prefetched;
-        if (nd > d->host_dets_cap) have = 0;  // the staging buffer is about to be replaced
-        int rc = ensure_host_dets(d, nd);
+        if (nd > d->host_cap) have = 0;  // the staging buffers are about to be replaced
+        int rc = ensure_host_out(d, nd, (size_t)g.nframes);
         if (rc) return rc;
-        HIPCHK(hipMemcpy(d->host_dets + have, d->dets.p + have, (nd - have) * sizeof(DetRec), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(d->host_det + have, d->out_det.p + have, (nd - have) * sizeof(DetOut), hipMemcpyDeviceToHost));
+        if (cam) HIPCHK(hipMemcpy(d->host_pose + have, d->out_pose.p + have, (nd - have) * sizeof(PoseOut), hipMemcpyDeviceToHost));
     }
     d->nd_guess = nd + nd / 4 + 256;
     clk::time_point t3 = clk::now();
-    // order by (frame, cluster key) = the oracle's visiting order; sort indices, not 330-byte records
-    const DetRec *hd = d->host_dets;
-    // the cluster key carries the frame in its top 16 bits, so sorting (key, index) pairs orders by (frame, cluster)
-    std::vector<std::pair<unsigned long long, unsigned int>> keyed(nd);
-    for (size_t k = 0; k < nd; k++) keyed[k] = std::make_pair((unsigned long long)hd[k].key, (unsigned int)k);
-    std::sort(keyed.begin(), keyed.end());
-    std::vector<unsigned int> order(nd);
-    for (size_t k = 0; k < nd; k++) order[k] = keyed[k].second;
-    std::vector<unsigned int> fin, one;
-    fin.reserve(nd);
-    std::vector<int> counts((size_t)g.nframes, 0);
-    size_t i = 0;
-    while (i < nd) {
-        size_t j = i;
-        int fr = hd[order[i]].frame;
-        one.clear();
-        while (j < nd && hd[order[j]].frame == fr) one.push_back(order[j++]);
-        size_t before = fin.size();
-        dedup_frame(hd, one, fin);
-        if (fr >= 0 && fr < g.nframes) counts[(size_t)fr] = (int)(fin.size() - before);
-        i = j;
-    }
-    int total = (int)fin.size();
+    // the device has de-duplicated, ordered by (frame, id) and laid the results out in the ABI's structs
+    static_assert(sizeof(DetOut) == sizeof(asl_detection) && sizeof(PoseOut) == sizeof(asl_pose), "device results are copied verbatim");
+    int total = (int)nd;
     int nw = std::min(total, max_out);
-    for (int k = 0; k < nw; k++) {
-        const DetRec &r = hd[fin[(size_t)k]];
-        if (out) {
-            asl_detection &o = out[k];
-            o.id = r.id; o.hamming = r.hamming; o.margin = r.margin; o.frame = r.frame;
-            memcpy(o.center, r.center, sizeof o.center);
-            memcpy(o.corners, r.corners, sizeof o.corners);
-        }
-        if (poses && cam) {
-            asl_pose &p = poses[k];
-            memcpy(p.rvec, r.rvec, sizeof p.rvec);
-            memcpy(p.tvec, r.tvec, sizeof p.tvec);
-            memcpy(p.T, r.T, sizeof p.T);
-            p.ok = r.pose_ok; p.reserved = 0;
-        }
-    }
-    if (n_per_frame) for (int f = 0; f < g.nframes; f++) n_per_frame[f] = counts[(size_t)f];
+    if (out && nw > 0) memcpy(out, d->host_det, (size_t)nw * sizeof(asl_detection));
+    if (poses && cam && nw > 0) memcpy(poses, d->host_pose, (size_t)nw * sizeof(asl_pose));
+    if (n_per_frame) for (int f = 0; f < g.nframes; f++) n_per_frame[f] = (int)d->host_nkeep[f];
     if (n_out) *n_out = total;
     d->host_ms[0] = msf(t0, t1); d->host_ms[1] = msf(t1, t2); d->host_ms[2] = msf(t2, t3); d->host_ms[3] = msf(t3, clk::now());
     return ASL_OK;

@@ -105,7 +105,9 @@ enum {
     CNT_CLASS4,
     CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
     CNT_UF_GUARD,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
-    CNT__N = 16
+    CNT_NKEEP,        // detections that survive the de-duplication (what the caller receives)
+    CNT_DEDUP_LIMIT,  // frames with more detections than the de-duplication sorts (fails the batch loudly)
+    CNT__N = 24
 };
 
 // A batch whose work buffers overflowed is re-run by the host after growing them; until then its cluster
