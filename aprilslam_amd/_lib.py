@@ -27,6 +27,8 @@ class AslDebugQuad(C.Structure):
     _fields_ = [("p", (C.c_double * 2) * 4), ("cluster", C.c_uint64), ("frame", C.c_int32), ("reversed_border", C.c_int32)]
 
 
+OBS_DTYPE = np.dtype([("id", "<i4"), ("flags", "<i4"), ("corners", "<f4", (8,)), ("T", "<f8", (12,))])  # asl_obs
+assert OBS_DTYPE.itemsize == 136
 DET_DTYPE = np.dtype([("id", "<i4"), ("hamming", "<i4"), ("margin", "<f4"), ("frame", "<i4"),
                       ("center", "<f8", (2,)), ("corners", "<f8", (4, 2))])
 POSE_DTYPE = np.dtype([("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)), ("T", "<f8", (4, 4)), ("ok", "<i4"), ("reserved", "<i4")])
@@ -37,7 +39,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -79,6 +81,8 @@ def load():
     L.asl_solve_pnp_batch.argtypes = [vp, C.POINTER(C.c_float), dp, dp, i32, C.c_double, dp, dp, dp, u8p, i32]
     L.asl_gn_solve.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_double, i32,
                                dp, dp, i32, dp]
+    L.asl_pack_observations_device.argtypes = [vp, vp, i32, vp]
+    L.asl_graph_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
     L.asl_debug_fetch.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.asl_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32, C.POINTER(i32)]
     L.asl_set_profiling.argtypes = [vp, i32]
@@ -221,6 +225,19 @@ class Detector:
         check(self._L.asl_submit_batch_device(self._h, C.c_void_p(int(data_ptr)), n_frames, channels, width, height, stride,
                                               frame_pitch, C.c_void_p(int(stream)), Kp, dpp, nd, float(tag_size)))
         self._inflight = (n_frames, K is not None)
+
+    def pack_observations_device(self, out_ptr, max_tags, stream=0):
+        """asl_pack_observations_device: the submitted batch's results as n_frames x max_tags asl_obs records at the
+        device address `out_ptr`, enqueued on `stream` (use the stream the batch was submitted on)."""
+        check(self._L.asl_pack_observations_device(self._h, C.c_void_p(int(out_ptr)), int(max_tags), C.c_void_p(int(stream))))
+
+    def graph_frames_device(self, obs_ptr, world, n_frames, max_tags, coordinate_id, pose_ptr, status_ptr, last_ptr, n_ids, picks_ptr=0,
+                            stream=0):
+        """asl_graph_frames_device (all pointers are device addresses; picks_ptr = 0 skips the picks)."""
+        check(self._L.asl_graph_frames_device(self._h, C.c_void_p(int(obs_ptr)), int(world), int(n_frames), int(max_tags),
+                                              int(coordinate_id), C.c_void_p(int(pose_ptr)), C.c_void_p(int(status_ptr)),
+                                              C.c_void_p(int(last_ptr)), int(n_ids), C.c_void_p(int(picks_ptr)) if picks_ptr else None,
+                                              C.c_void_p(int(stream))))
 
     def collect(self, max_per_frame=64):
         """Wait for the submitted batch; returns (dets, poses or None, n_per_frame).  The arrays are views into

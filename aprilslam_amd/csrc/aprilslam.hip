@@ -23,6 +23,7 @@
 #include "k_decode.inc"
 #include "k_pnp.inc"
 #include "k_dedup.inc"
+#include "k_graph.inc"
 #include "k_gn.inc"
 
 static thread_local std::string g_err;
@@ -83,6 +84,7 @@ struct asl_detector {
     DevBuf<double> pnp_out;
     DevBuf<uint8_t> pnp_ok;
     GnWorkspace gn;
+    hipStream_t aux_stream = nullptr;  // highest priority, for the small latency-bound jobs next to a running batch (pose-graph LM)
 
     // sizes used by the last batch
     Geom last{};
@@ -179,6 +181,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
+    if (d->aux_stream) (void)hipStreamDestroy(d->aux_stream);
     if (d->d_codes) (void)hipFree(d->d_codes);
     if (d->host_det) (void)hipHostFree(d->host_det);
     if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
@@ -658,6 +661,37 @@ extern "C" int asl_detect_bgr_u8(asl_detector *d, const uint8_t *bgr, int w, int
 {
     const uint8_t *fr[1] = {bgr};
     return asl_detect_batch_u8(d, fr, 1, 3, w, h, stride, out, max_out, nullptr, n_out);
+}
+
+extern "C" int asl_pack_observations_device(asl_detector *d, void *d_obs, int max_tags, void *stream)
+{
+    if (!d || !d_obs) return fail(ASL_EINVAL, "NULL detector or output");
+    if (max_tags <= 0) return fail(ASL_EINVAL, "max_tags must be positive");
+    if (!d->pending) return fail(ASL_EINVAL, "no batch in flight on this detector: pack between submit and the next submit");
+    static_assert(sizeof(ObsRec) == sizeof(asl_obs) && sizeof(asl_obs) == 136, "asl_obs layout");
+    HIPCHK(hipSetDevice(d->device));
+    const int nf = d->p_geom.nframes;
+    const unsigned int total = (unsigned int)nf * (unsigned int)max_tags;
+    hipLaunchKernelGGL(k_obs_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->dets.p, d->frame_idx.p, d->dets_per_frame,
+                       d->frame_nkeep.p, d->counters.p, (ObsRec *)d_obs, nf, max_tags);
+    HIPCHK(hipGetLastError());
+    return ASL_OK;
+}
+
+extern "C" int asl_graph_frames_device(asl_detector *d, const void *d_obs, int world, int n_frames, int max_tags, int coordinate_id,
+                                       double *d_pose, uint8_t *d_status, uint32_t *d_last, int n_ids, void *d_picks, void *stream)
+{
+    if (!d || !d_obs || !d_pose || !d_status || !d_last) return fail(ASL_EINVAL, "NULL argument");
+    if (world <= 0 || n_frames <= 0 || max_tags <= 0 || n_ids <= 0) return fail(ASL_EINVAL, "sizes must be positive");
+    HIPCHK(hipSetDevice(d->device));
+    const unsigned int total = (unsigned int)world * (unsigned int)n_frames;
+    hipLaunchKernelGGL(k_graph_frames, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
+                       coordinate_id, d_pose, d_status, (unsigned int *)d_last, n_ids);
+    if (d_picks)
+        hipLaunchKernelGGL(k_graph_pick, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
+                           (const unsigned int *)d_last, n_ids, (ObsRec *)d_picks);
+    HIPCHK(hipGetLastError());
+    return ASL_OK;
 }
 
 extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const double *K, const double *dist, int n_dist,

@@ -1,16 +1,27 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, frames (or whole streams) are
-independent until the graph update, which needs every observation in frame order
-(SURVEY.md section 8e).  The only exchange is one all-gather of fixed-size padded observation
-records per step -- a few KB per rank, latency-bound, so a single flat all-gather (RCCL's direct
-algorithm over the fully connected xGMI mesh), never a ring of large buckets.
+"""Multi-GPU sharding of the hot path: one process per GPU, frames (or whole streams) are independent until the
+graph update, which needs every observation in frame order.
 
-Record layout (float64, OBS_WIDTH values per tag slot):
-    [valid, stream, frame, id, corners(8), T(16)]
-`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU in the tests.
+The only exchange is one flat all-gather per step of fixed-size padded observation records (`asl_obs`, 136 bytes per
+tag slot: id, flags, 8 float32 corners, 12 float64 of T).  The records are packed ON THE DEVICE from the detector's
+results (asl_pack_observations_device) and gathered with `all_gather_into_tensor` -- RCCL over xGMI with backend
+"nccl", gloo on CPU tensors in the tests; the payload is a few MB per rank and step, so a single flat collective,
+never a ring of buckets.
+
+After the gather every rank holds the same block and updates its own copy of the graph:
+  * `graph_frames` (device kernel k_graph_frames / numpy mirror `graph_frames_numpy`): per frame, whether its update is
+    self-contained (the world tag is its lowest id and no PnP failed: branches A / C1 of slam_graph.py:33-49), its
+    camera pose, and per tag the last such frame in (frame, stream) order;
+  * `apply_block` turns that into the state the sequential reference update would have reached: node values from the
+    last frame that saw each tag (computed on the host with the reference's own float64 operations), and falls back
+    to the sequential mirror, frame by frame, whenever a frame is not self-contained.
 """
 import numpy as np
 
-OBS_WIDTH = 4 + 8 + 16
+from . import _lib
+from .slam_graph import Node
+
+OBS_DTYPE = _lib.OBS_DTYPE
+MAX_IDS = 4096  # size of the per-tag "last seen" table
 
 
 def shard_frames(n_frames, rank, world_size):
@@ -18,115 +29,204 @@ def shard_frames(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
-def pack_observations(dets, poses, n_per_frame, stream_id, max_tags, frame_offset=0, out=None):
-    """Structured detection/pose arrays of one step -> (n_frames, max_tags, OBS_WIDTH) float64, zero padded.
-    Vectorised (at 1024 frames x 20 tags a per-frame Python loop costs more than the GPU step it follows); pass the
-    previous result as `out` to reuse its memory (a fresh 5 MB array costs milliseconds of page faults)."""
+def pack_observations(dets, poses, n_per_frame, max_tags):
+    """Host-side packing of one step's structured detection/pose arrays into (n_frames, max_tags) asl_obs records --
+    the layout asl_pack_observations_device produces on the GPU (used by the CPU tests and host-only callers).
+    Detections beyond max_tags per frame are dropped; `poses` is required (an observation without a transform cannot
+    update the graph)."""
+    if poses is None:
+        raise ValueError("pack_observations needs the poses: a record without a transform cannot update the graph")
     npf = np.asarray(n_per_frame, dtype=np.int64)
     n_frames = len(npf)
-    if out is not None and out.shape == (n_frames, max_tags, OBS_WIDTH) and out.dtype == np.float64:
-        out.fill(0.0)
-    else:
-        out = np.zeros((n_frames, max_tags, OBS_WIDTH), dtype=np.float64)
+    out = np.zeros((n_frames, max_tags), dtype=OBS_DTYPE)
+    out["id"] = -1
     total = int(npf.sum())
     if total == 0:
         return out
-    c = int(npf[0])
-    if c <= max_tags and np.all(npf == c):                # every frame holds the same number of tags: plain slices
-        out[:, :c, 0] = 1.0 if poses is None else poses["ok"][:total].reshape(n_frames, c)
-        out[:, :c, 1] = stream_id
-        out[:, :c, 2] = (frame_offset + np.arange(n_frames))[:, None]
-        out[:, :c, 3] = dets["id"][:total].reshape(n_frames, c)
-        out[:, :c, 4:12] = dets["corners"][:total].reshape(n_frames, c, 8)
-        if poses is not None:
-            out[:, :c, 12:28] = poses["T"][:total].reshape(n_frames, c, 16)
-        return out
     starts = np.concatenate(([0], np.cumsum(npf)[:-1]))
-    frame = np.repeat(np.arange(n_frames), npf)           # frame of every detection (detections are frame-ordered)
-    slot = np.arange(total) - np.repeat(starts, npf)      # its position inside the frame
+    frame = np.repeat(np.arange(n_frames), npf)
+    slot = np.arange(total) - np.repeat(starts, npf)
     keep = slot < max_tags
-    sel = slice(None) if keep.all() else keep             # field-wise selection: no copy of whole records
-    flat = (frame * max_tags + slot)[sel]
-    o = out.reshape(n_frames * max_tags, OBS_WIDTH)
-    o[flat, 0] = 1.0 if poses is None else poses["ok"][:total][sel]
-    o[flat, 1] = stream_id
-    o[flat, 2] = frame_offset + frame[sel]
-    o[flat, 3] = dets["id"][:total][sel]
-    o[flat, 4:12] = dets["corners"][:total][sel].reshape(-1, 8)
-    if poses is not None:
-        o[flat, 12:28] = poses["T"][:total][sel].reshape(-1, 16)
+    f, s = frame[keep], slot[keep]
+    out["id"][f, s] = dets["id"][:total][keep]
+    out["flags"][f, s] = 1 | (2 * (poses["ok"][:total][keep] != 0))
+    out["corners"][f, s] = dets["corners"][:total][keep].reshape(-1, 8).astype(np.float32)
+    out["T"][f, s] = poses["T"][:total][keep].reshape(-1, 16)[:, :12]
     return out
 
 
-_gather_cache = {}
-
-
-def pinned_observation_buffer(n_frames, max_tags):
-    """A page-locked (n_frames, max_tags, OBS_WIDTH) float64 numpy array to pack into (pack_observations(out=...)):
-    the H2D copy of the all-gather then runs at full PCIe speed and without a staging copy."""
-    import torch
-
-    t = torch.empty((n_frames, max_tags, OBS_WIDTH), dtype=torch.float64)
-    if torch.cuda.is_available():
-        t = t.pin_memory()
-    _gather_cache[("in", t.data_ptr())] = t  # keep the storage alive as long as the module
-    return t.numpy()
-
-
-def all_gather_observations(local_obs, device=None, wait=True):
-    """All ranks contribute an equally shaped record block; returns (world, n_frames, max_tags, OBS_WIDTH)
-    as a numpy array, identical on every rank.  Falls back to the local block when not distributed.
-    With a CUDA `device` the gathered block comes back through cached page-locked buffers (two, used alternately):
-    the returned array is a view of one, valid until the call after next with the same shape.  wait=False returns
-    (array, event) right after enqueueing the read-back; the array may be read once event.synchronize() returned."""
+def all_gather_observations(local_obs):
+    """local_obs: (n_frames, max_tags) asl_obs records as a numpy structured array or as a torch uint8 tensor
+    (n_frames, max_tags, 136) on the device.  Returns the same kind with a leading `world` axis, identical on every
+    rank: ONE all_gather_into_tensor.  Without an initialised process group the block is returned with world = 1."""
     import torch
     import torch.distributed as dist
 
+    is_np = isinstance(local_obs, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(local_obs).view(np.uint8).reshape(local_obs.shape + (OBS_DTYPE.itemsize,))) if is_np else local_obs
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local_obs[None]
-    t = torch.from_numpy(np.ascontiguousarray(local_obs))
-    world = dist.get_world_size()
-    if device is None:
-        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype)
-        dist.all_gather([out[r] for r in range(world)], t)
-        return out.numpy()
-    key = (str(device), world) + tuple(t.shape)
-    bufs = _gather_cache.get(key)
-    if bufs is None:
-        bufs = {"d_in": torch.empty(tuple(t.shape), dtype=t.dtype, device=device),
-                "d_out": torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device),
-                "h_out": [torch.empty((world,) + tuple(t.shape), dtype=t.dtype).pin_memory() for _ in range(2)],
-                "turn": 0}
-        _gather_cache[key] = bufs
-    d_in, d_out = bufs["d_in"], bufs["d_out"]
-    h_out = bufs["h_out"][bufs["turn"]]
-    bufs["turn"] ^= 1
-    d_in.copy_(t, non_blocking=True)
-    # one flat all-gather; the output rows are views of one contiguous block
-    dist.all_gather([d_out[r] for r in range(world)], d_in)
-    h_out.copy_(d_out, non_blocking=True)
-    if not wait:
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        return h_out.numpy(), ev
-    torch.cuda.current_stream(device).synchronize()
-    return h_out.numpy()
+        out = t[None]
+    else:
+        world = dist.get_world_size()
+        flat = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(flat, t.contiguous().view(-1))  # flat in, flat out: the form every backend accepts
+        out = flat.view((world,) + tuple(t.shape))
+    if is_np:
+        return out.numpy().view(OBS_DTYPE).reshape(out.shape[:-1])
+    return out
 
 
-def apply_observations(slam, gathered):
-    """Deterministic global update: observations applied in (frame, stream, id) order to one SLAM
-    graph (identical on every rank).  Returns the list of my_pose() results per (frame, stream)."""
-    world, n_frames, max_tags, _ = gathered.shape
+class ObsBlock:
+    """A gathered block obs[world][n_frames][max_tags] that lives either on the host (numpy asl_obs records) or on the
+    device (torch uint8 tensor (world, n_frames, max_tags, 136)).  The bulk update touches only a handful of frames of
+    it (the last sighting of every tag), so a device block is never copied to the host as a whole unless the sequential
+    fall-back needs it."""
+
+    def __init__(self, data):
+        self.data = data
+        self.on_host = isinstance(data, np.ndarray)
+        self.shape = tuple(data.shape[:3])
+        self._host = data if self.on_host else None
+
+    def frames(self, pairs):
+        """records (len(pairs), max_tags) of the (stream, frame) pairs, one copy"""
+        if self._host is not None:
+            return np.stack([self._host[s, f] for s, f in pairs]) if len(pairs) else np.zeros((0, self.shape[2]), OBS_DTYPE)
+        import torch
+        world, n_frames, max_tags = self.shape
+        idx = torch.tensor([s * n_frames + f for s, f in pairs], dtype=torch.int64, device=self.data.device)
+        rows = self.data.view(world * n_frames, max_tags, -1).index_select(0, idx).cpu().numpy()
+        return rows.reshape(-1).view(OBS_DTYPE).reshape(len(pairs), max_tags)
+
+    def host(self):
+        if self._host is None:
+            a = self.data.cpu().numpy()
+            self._host = a.reshape(-1).view(OBS_DTYPE).reshape(self.shape)
+        return self._host
+
+
+def _full(T12):
+    T = np.zeros(T12.shape[:-1] + (4, 4))
+    T[..., :3, :] = T12.reshape(T12.shape[:-1] + (3, 4))
+    T[..., 3, 3] = 1.0
+    return T
+
+
+def graph_frames_numpy(obs, coordinate_id, n_ids=MAX_IDS):
+    """Host mirror of asl_graph_frames_device on obs[world][n_frames][max_tags]: (pose (world, n_frames, 4, 4), status
+    (world, n_frames) uint8, last (n_ids,) uint32), same definitions (include/aprilslam.h)."""
+    world, n_frames, max_tags = obs.shape
+    used = (obs["flags"] & 1) != 0
+    n = used.sum(axis=2)
+    ok = (((obs["flags"] & 2) != 0) & (obs["id"] >= 0) & (obs["id"] < n_ids)) | ~used
+    steady = (coordinate_id >= 0) & ok.all(axis=2) & (n > 0) & (obs["id"][:, :, 0] == coordinate_id)
+    status = np.where(n == 0, 2, np.where(steady, 0, 1)).astype(np.uint8)
+    pose = np.zeros((world, n_frames, 4, 4))
+    last = np.zeros(n_ids, dtype=np.uint32)
+    if steady.any():
+        T = _full(obs["T"])                                   # (world, n_frames, max_tags, 4, 4)
+        with np.errstate(all="ignore"):
+            Ts = np.where(used[..., None, None], T, np.eye(4))
+            local = np.linalg.inv(Ts[steady])                 # (S, max_tags, 4, 4)
+        lc = local[:, :1]
+        vote = (lc @ Ts[steady]) @ local                      # world_j @ local_j; slot 0 gives I @ inv(T_c)
+        vote[:, 0] = local[:, 0]
+        u = used[steady]
+        acc = np.zeros((vote.shape[0], 4, 4))
+        for j in range(max_tags):                             # the reference's accumulation order: slot by slot
+            acc += np.where(u[:, j, None, None], vote[:, j], 0.0)
+        pose[steady] = acc / n[steady][:, None, None]
+        s_idx, f_idx = np.nonzero(steady)
+        order = (f_idx * world + s_idx).astype(np.uint64) * max_tags
+        ids = obs["id"][steady]
+        for j in range(max_tags):
+            sel = u[:, j]
+            np.maximum.at(last, ids[sel, j], (order[sel] + j + 1).astype(np.uint32))
+    return pose, status, last
+
+
+def _sequential(slam, obs, frames):
+    """The reference's own update, frame by frame, for `frames` = iterable of (stream, frame) in order."""
     poses = []
-    for f in range(n_frames):
-        for s in range(world):
-            rec = gathered[s, f]
-            rec = rec[rec[:, 0] > 0]
-            if len(rec) == 0:
-                slam.visible_tags = []
-                poses.append(None)
-                continue
-            order = np.argsort(rec[:, 3], kind="stable")
-            rec = rec[order]
-            poses.append(slam.process_observations(rec[:, 3].astype(int).tolist(), rec[:, 12:28].reshape(-1, 4, 4)))
+    for s, f in frames:
+        rec = obs[s, f]
+        rec = rec[(rec["flags"] & 1) != 0]
+        if len(rec) == 0:
+            slam.visible_tags = []
+            poses.append(None)
+            continue
+        # every detected id is "visible" (slam.py:24); only tags whose PnP succeeded update the graph (slam.py:30-31)
+        poses.append(slam.process_observations(rec["id"].tolist(), _full(rec["T"]), oks=(rec["flags"] & 2) != 0))
     return poses
+
+
+def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
+    """Apply one gathered block (numpy asl_obs records [world][n_frames][max_tags], or an ObsBlock) to `slam` in
+    (frame, stream) order, deterministically and identically on every rank.  frames_result = (pose, status, last) of
+    graph_frames (device kernel or numpy mirror) for this block and slam.coordinate_id; computed here with numpy if
+    omitted.  picks (2 * n_ids asl_obs, from asl_graph_frames_device) and tail (the records of the last frame of every
+    stream, (world, max_tags)) spare the bulk path every access to the block itself.
+    Returns (poses (world, n_frames, 4, 4), NaN where my_pose() is None; frames that took the sequential path)."""
+    blk = obs if isinstance(obs, ObsBlock) else ObsBlock(obs)
+    world, n_frames, max_tags = blk.shape
+    order = [(s, f) for f in range(n_frames) for s in range(world)]
+    out = np.full((world, n_frames, 4, 4), np.nan)
+    if slam.coordinate_id == -1:
+        # nothing is self-contained before a world tag exists: the whole block goes through the mirror (once per run)
+        for (s, f), p in zip(order, _sequential(slam, blk.host(), order)):
+            if p is not None:
+                out[s, f] = p
+        return out, len(order)
+    if frames_result is None:
+        frames_result = graph_frames_numpy(blk.host(), slam.coordinate_id)
+    pose, status, last = frames_result
+    pose = np.asarray(pose).reshape(world, n_frames, 4, 4)
+    status = np.asarray(status).reshape(world, n_frames)
+    if not (status == 1).any():
+        _apply_steady(slam, blk, status, np.asarray(last), world, n_frames, max_tags, picks, tail)
+        good = status == 0
+        out[good] = pose[good]
+        return out, 0
+    # some frame needs the reference's sequential update: the state it reads depends on everything before it, so the
+    # block goes through the mirror in order
+    for (s, f), p in zip(order, _sequential(slam, blk.host(), order)):
+        if p is not None:
+            out[s, f] = p
+    return out, len(order)
+
+
+def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None, tail=None):
+    """State after a block of self-contained frames: every tag carries the values of the last frame that saw it, computed
+    with the reference's operations (inv, @) on the host -- bit-identical to the sequential update."""
+    c = slam.coordinate_id
+    graph = slam.graph
+    ids = np.nonzero(last)[0]
+    keys = last[ids].astype(np.int64) - 1
+    slots = keys % max_tags
+    orders = keys // max_tags
+    # the last frame with detections leaves its ids visible and its pose in estimated_pose (slam.py:36-63)
+    nz = np.argwhere(status.T != 2)  # (frame, stream) pairs, frame-major
+    tail_pair = (int(nz[-1][1]), int(nz[-1][0])) if len(nz) else None
+    if picks is None:
+        pairs = [(int(o % world), int(o // world)) for o in orders]
+        recs = blk.frames(pairs)
+        own = [recs[k][slots[k]] for k in range(len(ids))]
+        ref = [recs[k][0] for k in range(len(ids))]
+    else:
+        own = [picks[2 * int(t)] for t in ids]
+        ref = [picks[2 * int(t) + 1] for t in ids]
+    for k, tag_id in enumerate(ids):
+        T = _full(own[k]["T"])
+        if tag_id == c:
+            graph.graph[int(tag_id)] = Node(graph.invert(T), np.eye(4), int(tag_id))
+        else:
+            graph.graph[int(tag_id)] = Node(graph.invert(T), graph.invert(_full(ref[k]["T"])) @ T, c)
+    if tail_pair is not None:
+        if tail is not None and tail_pair[1] == n_frames - 1:
+            rec = tail[tail_pair[0]]
+        else:
+            rec = blk.frames([tail_pair])[0]
+        rec = rec[(rec["flags"] & 1) != 0]
+        slam.visible_tags = rec["id"].tolist()
+        graph.visible_tags = slam.visible_tags
+        slam.my_pose()

@@ -35,6 +35,7 @@ class SLAMGraph:
         self.visible_tags = []
         self.coordinate_id = -1
         self.estimated_pose = np.zeros((4, 4))
+        self.world_updater = None  # set by SLAM(window=N): what the reference's update_world stub was meant to become
 
     # -- small helpers (same names as the reference) ---------------------------------
     def invert(self, T):
@@ -49,8 +50,12 @@ class SLAMGraph:
         return world, ref.weight + 1, ref.reference
 
     def update_world(self):
-        # the reference leaves this unimplemented and announces it (slam_graph.py:72-76)
-        print("No world update")
+        # the reference leaves this unimplemented and announces it (slam_graph.py:72-76); with a back-end attached the
+        # map is re-optimised instead
+        if self.world_updater is None:
+            print("No world update")
+        else:
+            self.world_updater()
 
     # -- the per-observation update --------------------------------------------------
     def add_or_update_node(self, tag_id, T, visible_tags):

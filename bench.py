@@ -4,10 +4,12 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-A step = one batch of B synthetic BGR frames through asl_detect_batch_device (threshold ->
-components -> clusters -> quads -> decode -> PnP, detections and poses copied back, host
-dedup/sort).  For N > 1 every rank runs its own stream of B frames per step (weak scaling) and
-the ranks all-gather their observation records (RCCL) inside the timed region.
+A step = one batch of B synthetic BGR frames through asl_detect_batch_device (threshold -> components ->
+clusters -> quads -> decode -> PnP -> de-duplication, results copied back).  With --gpus N > 1 the script starts N
+ranks itself (or runs as one rank of a torchrun launch); every rank runs its own stream of B frames per step (weak
+scaling), and inside the timed region the ranks all-gather their observation records (packed on the device, one RCCL
+all_gather_into_tensor), apply the gathered block to the tag graph (k_graph_frames + the last-sighting update) and
+every --gn-every steps run the pose-graph LM on a window -- the serial term the scaling curve pays for.
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
 """
 import argparse
@@ -26,14 +28,16 @@ TAG_OUTER, TAG_INNER = 18.0, 10.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_frames(n_distinct, seed=20250620 + 1, with_gt=False):
-    """n_distinct frames of one seeded 20-tag scene seen from a smooth camera trajectory."""
+def make_frames(n_distinct, seed=20250620 + 1, with_gt=False, phase=0.0):
+    """n_distinct frames of one seeded 20-tag scene seen from a smooth camera trajectory.  `phase` shifts the camera
+    along the trajectory: the streams of a multi-GPU run look at the SAME tags from different places, so that the
+    gathered observations describe one map."""
     from aprilslam_amd import synth
     rng = np.random.default_rng(seed)
     tags = synth.random_scene(W, H, NTAGS, rng, tag_size_outer=TAG_OUTER)
     frames, gts = [], []
     for i in range(n_distinct):
-        a = 2 * np.pi * i / max(n_distinct, 1)
+        a = 2 * np.pi * i / max(n_distinct, 1) + phase
         pos = (1.5 * np.cos(a), 1.0 * np.sin(a), 2.0 * np.sin(2 * a))
         rot = (0.6 * np.sin(a), 0.8 * np.cos(a), 0.5 * np.sin(3 * a))
         f, gt = synth.render_frame(W, H, tags, TAG_OUTER, cam_position=pos, cam_rotation_deg=rot)
@@ -138,6 +142,27 @@ def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
     return out
 
 
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: N fresh children, one per GPU, started BEFORE this process touches the GPU; rank 0's
+    stdout (the JSON line) is passed through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rc = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(c) for c in rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,12 +173,21 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
+    ap.add_argument("--max-tags", type=int, default=NTAGS + 4, help="tag slots per frame in the exchanged observation records")
+    ap.add_argument("--gn-every", type=int, default=50, help="N > 1: pose-graph LM on a window every this many steps (0 = never)")
+    ap.add_argument("--gn-frames", type=int, default=8, help="frames per stream in the LM window")
+    ap.add_argument("--exchange", action="store_true", help="N = 1: run the exchange + graph update + LM of the multi-GPU step anyway (the collective degenerates to a copy)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or let --gpus start the ranks)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.rehearse:
@@ -171,7 +205,8 @@ def main():
     from aprilslam_amd import dist as adist
 
     K = synth.camera_matrix(W, H)
-    distinct, distinct_gt = make_frames(args.distinct, seed=20250620 + 1 + rank, with_gt=True)  # each rank = its own stream
+    distinct, distinct_gt = make_frames(args.distinct, with_gt=True, phase=2 * np.pi * rank / max(world, 1) / max(args.distinct, 1) * 0.5)  # each rank = its own camera, one scene
+    xchg = world > 1 or args.exchange  # the part of a step that needs every rank
     B = args.batch
     reps = (B + len(distinct) - 1) // len(distinct)
     d_frames = torch.from_numpy(distinct).to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
@@ -187,20 +222,92 @@ def main():
     zeros4 = np.zeros(4)
     state = {"i": 0, "inflight": []}
 
+    MT = args.max_tags
+    slam = None
+    xb = []  # per pipeline part: the buffers of the exchange
+    if xchg:
+        from aprilslam_amd.slam import SLAM
+
+        class _Log:
+            def info(self, m):
+                pass
+        slam = SLAM(_Log(), {"camera_matrix": K, "dist_coeffs": np.zeros(4)}, tag_size=TAG_INNER, detector=object())
+        for _ in range(P):
+            xb.append({"obs": torch.empty((B, MT, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                       "pose": torch.zeros((world * B, 16), dtype=torch.float64, device=dev),
+                       "status": torch.zeros(world * B, dtype=torch.uint8, device=dev),
+                       "last": torch.zeros(adist.MAX_IDS, dtype=torch.int32, device=dev),
+                       "h_pose": torch.zeros((world * B, 16), dtype=torch.float64).pin_memory(),
+                       "h_status": torch.zeros(world * B, dtype=torch.uint8).pin_memory(),
+                       "h_last": torch.zeros(adist.MAX_IDS, dtype=torch.int32).pin_memory(),
+                       "picks": torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                       "h_picks": torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory(),
+                       "h_tail": torch.zeros((world, MT + args.gn_frames * MT, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory(),
+                       "block": None, "cid": -2})
+    serial = {"gather": [], "graph": [], "gn": [], "seq_frames": 0, "gn_runs": 0}
+
+    def enqueue_exchange(k):
+        """Stream-ordered behind batch k, no host wait: pack the records on the device, all-gather them, run the per-frame
+        graph kernel for the current world tag and start the read-back of its (small) results."""
+        x = xb[k]
+        detectors[k].pack_observations_device(x["obs"].data_ptr(), MT, stream=streams[k].cuda_stream)
+        if args.rehearse:
+            return  # gloo gathers host memory: done after the batch has been collected
+        with torch.cuda.stream(streams[k]):
+            x["block"] = adist.all_gather_observations(x["obs"])
+            x["cid"] = slam.coordinate_id
+            if x["cid"] != -1:
+                x["last"].zero_()
+                detectors[k].graph_frames_device(x["block"].data_ptr(), world, B, MT, x["cid"], x["pose"].data_ptr(), x["status"].data_ptr(),
+                                                 x["last"].data_ptr(), adist.MAX_IDS, picks_ptr=x["picks"].data_ptr(), stream=streams[k].cuda_stream)
+                x["h_pose"].copy_(x["pose"], non_blocking=True)
+                x["h_status"].copy_(x["status"], non_blocking=True)
+                x["h_last"].copy_(x["last"], non_blocking=True)
+                x["h_picks"].copy_(x["picks"], non_blocking=True)
+            # the last frames of every stream: the tail of the update and the LM window
+            nt = 1 + args.gn_frames
+            x["h_tail"][:, :nt * MT].copy_(x["block"][:, B - nt:].reshape(world, nt * MT, -1), non_blocking=True)
+
+    def update_graph(k):
+        """Host part, after batch k has been collected (its stream has drained): apply the gathered block to the graph."""
+        x = xb[k]
+        t0 = time.perf_counter()
+        res = None
+        if args.rehearse:
+            block = adist.ObsBlock(adist.all_gather_observations(x["obs"].cpu().numpy().reshape(-1).view(adist.OBS_DTYPE).reshape(B, MT)))
+        else:
+            block = adist.ObsBlock(x["block"])
+            if x["cid"] != -1 and x["cid"] == slam.coordinate_id:  # the kernel ran for the world tag the graph still has
+                res = (x["h_pose"].numpy(), x["h_status"].numpy(), x["h_last"].numpy().view(np.uint32))
+        picks = tail_frames = None
+        if res is not None:
+            nt = 1 + args.gn_frames
+            picks = x["h_picks"].numpy().reshape(-1).view(adist.OBS_DTYPE)
+            tail_frames = x["h_tail"].numpy()[:, :nt * MT].reshape(-1).view(adist.OBS_DTYPE).reshape(world, nt, MT)
+        t1 = time.perf_counter()
+        poses, nseq = adist.apply_block(slam, block, res, picks=picks, tail=None if tail_frames is None else tail_frames[:, -1])
+        t2 = time.perf_counter()
+        serial["gather"].append(t1 - t0); serial["graph"].append(t2 - t1); serial["seq_frames"] += nseq
+        state["blocks"] = state.get("blocks", 0) + 1
+        if args.gn_every and (state["blocks"] % args.gn_every == 0 or state["blocks"] == 2):  # block 2: warm-up run (allocates the LM workspace)
+            # window: the last frames of every stream in this block, initial guesses from the graph
+            pairs = [(s_, f_) for f_ in range(max(0, B - args.gn_frames), B) for s_ in range(world)]
+            recs = block.frames(pairs) if tail_frames is None else [tail_frames[s_, f_ - (B - 1 - args.gn_frames)] for s_, f_ in pairs]
+            cams, obs = [], []
+            for (s_, f_), rec in zip(pairs, recs):
+                rec = rec[(rec["flags"] & 3) == 3]
+                if len(rec) and not np.isnan(poses[s_, f_]).any():
+                    cams.append(poses[s_, f_])
+                    obs.append([(int(i), c.reshape(4, 2).astype(np.float64)) for i, c in zip(rec["id"], rec["corners"])])
+            if cams:
+                state["gn_last"] = slam.optimize_window(cams, obs, iters=2, backend=detectors[k])
+                serial["gn_runs"] += 1
+            serial["gn"].append(time.perf_counter() - t2)
+
     def finish(k):
         dets, poses, npf = detectors[k].collect()
-        if world > 1:
-            if "obs" not in state:
-                state["obs"] = adist.pinned_observation_buffer(B, NTAGS + 4) if not args.rehearse else None
-            if state.get("gather_ev") is not None:
-                # the previous step's exchange is complete: its H2D no longer reads the pack buffer and its gathered
-                # block has landed in host memory
-                state["gather_ev"].synchronize()
-            obs = adist.pack_observations(dets, poses, npf, rank, NTAGS + 4, out=state["obs"])
-            if args.rehearse:
-                adist.all_gather_observations(obs, device=None)
-            else:  # read-back of the gathered block overlaps the next step (it is consumed one step later)
-                _, state["gather_ev"] = adist.all_gather_observations(obs, device=dev, wait=False)
+        if xchg:
+            update_graph(k)
         for kk, v in detectors[k].stage_times().items():
             kernel_ms.setdefault(kk, []).append(v)
         return dets, npf
@@ -212,6 +319,8 @@ def main():
         if len(state["inflight"]) == P:
             finish(state["inflight"].pop(0))
         detectors[k].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[k].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
+        if xchg:
+            enqueue_exchange(k)
         state["inflight"].append(k)
 
     def drain():
@@ -230,6 +339,10 @@ def main():
     n_found = int(len(res[0])) if res else -1
 
     kernel_ms.clear()
+    for v in serial.values():
+        if isinstance(v, list):
+            v.clear()
+    serial["seq_frames"] = 0; serial["gn_runs"] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -294,6 +407,14 @@ def main():
             "data": "synthetic: %d distinct rendered frames of a seeded 20-tag scene tiled to %d frames per step, resident in HBM" % (len(distinct), B),
             "config": {"workload": "configs[1]: 1280x720 BGR stream, 20 tags/frame, detect + PnP", "batch_frames": B,
                        "decimate": 2, "tags_found_per_batch": n_found, "pipeline_parts": P, "parallelism": "1 video stream per GPU"},
+            "multi_gpu": None if not xchg else {
+                "exchange": "one all_gather_into_tensor per step of %d x %d asl_obs records (136 B) per rank = %.1f MB per rank, packed on the device" % (B, MT, B * MT * 136 / 1e6),
+                "backend": "gloo (rehearsal)" if args.rehearse else "nccl (RCCL)",
+                "serial_ms_per_step": {"gather_host_side": 1e3 * float(np.mean(serial["gather"])), "graph_update_host": 1e3 * float(np.mean(serial["graph"])),
+                                       "pose_graph_lm_per_run": (1e3 * float(np.mean(serial["gn"])) if serial["gn"] else None)},
+                "frames_through_sequential_update": serial["seq_frames"], "lm_runs": serial["gn_runs"],
+                "lm_last": {k_: v_ for k_, v_ in (state.get("gn_last") or {}).items() if k_ != "camera_poses"} or None,
+                "graph_nodes": len(slam.graph.get_nodes()), "world_tag": slam.coordinate_id},
             "roofline": roof,
             "stage_threshold_segmentation": {"ms_per_batch_isolated": seg, "algorithmic_read_bytes_per_frame": seg_bytes,
                                              "achieved_GBs": seg_gbs, "frac_of_hbm_peak": seg_gbs / HBM_PEAK_GBS},

@@ -141,6 +141,32 @@ int asl_gn_solve(asl_detector *det, int n_cams, int n_tags, int n_obs, const int
                  int fixed_tag, double *cam_T /*n_cams x 16*/, double *tag_T /*n_tags x 16*/, int iters,
                  double *stats /*3*/);
 
+/* ---- after the detector: what the multi-GPU path exchanges and how the graph update consumes it.
+   One observation = one detected tag of one frame: what SLAM.get_pose hands to SLAMGraph.add_or_update_node
+   (reference slam.py:27-32) plus the corners a later bundle adjustment needs. */
+typedef struct {
+    int32_t id;       /* -1 = empty slot */
+    int32_t flags;    /* bit 0: slot used; bit 1: solvePnP succeeded (the reference updates the graph only then) */
+    float corners[8]; /* lb, rb, rt, lt in pixels, float32 as the reference passes them to solvePnP */
+    double T[12];     /* rows 0..2 of the camera<-tag 4x4 (row 3 is 0 0 0 1) */
+} asl_obs;            /* 136 bytes */
+
+/* Packs the de-duplicated results of the batch last submitted on `det` into d_obs (device memory,
+   n_frames x max_tags records, slots ordered by id, empty slots id = -1) on `stream` -- no host round trip, so the
+   block can go straight into an all-gather.  Call between asl_submit_batch_device and the next submit. */
+int asl_pack_observations_device(asl_detector *det, void *d_obs, int max_tags, void *stream);
+
+/* The data-parallel part of the graph update over gathered records d_obs[world][n_frames][max_tags]:
+   d_pose[world*n_frames][16] = SLAM.my_pose() of every frame that (a) sees the world tag `coordinate_id` as its lowest id
+   and (b) has no failed PnP -- such a frame's update depends on nothing but the frame (branches A / C1 of
+   slam_graph.py:33-49); d_status = 0 for those, 1 for frames that need the sequential update, 2 for frames without
+   detections; d_last[id] (caller zeroes it) = 1 + ((frame*world + stream)*max_tags + slot) of the last status-0 frame,
+   in (frame, stream) order, that saw tag `id`; d_picks (optional, 2*n_ids asl_obs) receives for every such tag its
+   record in that frame and the frame's world-tag record -- all the host needs to finish the update without touching
+   the block again. */
+int asl_graph_frames_device(asl_detector *det, const void *d_obs, int world, int n_frames, int max_tags, int coordinate_id,
+                            double *d_pose, uint8_t *d_status, uint32_t *d_last, int n_ids, void *d_picks, void *stream);
+
 /* Introspection for the parity tests: copy an intermediate buffer of the LAST batch to host.
    what: 0 = decimated gray (u8, B*sh*sw)     1 = threshold image (u8, B*sh*sw)
          2 = component labels (u32, B*sh*sw)  3 = component sizes by label (u32, B*sh*sw)

@@ -51,43 +51,102 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from aprilslam_amd import dist as adist
     dets, poses, npf = _fake_step(rank)
-    obs = adist.pack_observations(dets, poses, npf, rank, max_tags=6)
-    gathered = adist.all_gather_observations(obs)
-    out[rank] = gathered
+    obs = adist.pack_observations(dets, poses, npf, max_tags=6)
+    gathered = adist.all_gather_observations(obs)        # numpy records -> gloo all_gather_into_tensor on their bytes
+    out[rank] = gathered.view(np.uint8).reshape(gathered.shape + (-1,))
     dist.destroy_process_group()
 
 
-def test_all_gather_and_ordered_update_two_ranks():
-    from aprilslam_amd import dist as adist
+def _blocks(rng, world, n_frames, max_tags, n_blocks, world_tag=0):
+    """Random gathered blocks: most frames self-contained (world tag present, every PnP ok), with an empty frame, a frame
+    that misses the world tag and one with a failed PnP thrown in."""
+    from aprilslam_amd import dist as adist, synth
+    out = []
+    for b in range(n_blocks):
+        obs = np.zeros((world, n_frames, max_tags), dtype=adist.OBS_DTYPE)
+        obs["id"] = -1
+        for s in range(world):
+            for f in range(n_frames):
+                ids = [world_tag] + sorted(rng.choice(np.arange(1, 9), size=rng.integers(1, max_tags - 1), replace=False).tolist())
+                if (b, s, f) == (2, 1, 2):
+                    ids = ids[1:]          # world tag out of view
+                if (b, s, f) == (1, 0, 3):
+                    ids = []               # nothing detected
+                for j, i in enumerate(ids):
+                    T = synth.camera_from_tag([rng.uniform(-20, 20), rng.uniform(-10, 10), -rng.uniform(40, 90)], rng.uniform(-20, 20, 3))
+                    obs["id"][s, f, j] = i
+                    obs["flags"][s, f, j] = 1 if (b, s, f, j) == (3, 0, 1, 1) else 3
+                    obs["corners"][s, f, j] = rng.uniform(0, 700, 8)
+                    obs["T"][s, f, j] = T[:3].ravel()
+        out.append(obs)
+    return out
+
+
+def _new_slam():
     from aprilslam_amd.slam import SLAM
-    world = 2
-    port = _free_port()
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    g0, g1 = out[0], out[1]
-    assert g0.shape == (2, 3, 6, adist.OBS_WIDTH)
-    assert np.array_equal(g0, g1), "ranks disagree on the gathered observations"
-    # the gathered block equals what each rank packed locally
-    for r in range(world):
-        dets, poses, npf = _fake_step(r)
-        assert np.array_equal(g0[r], adist.pack_observations(dets, poses, npf, r, max_tags=6))
 
     class Log:
         def info(self, m):
             pass
 
+    return SLAM(Log(), {"camera_matrix": np.eye(3), "dist_coeffs": np.zeros(4)}, detector=object())
+
+
+def test_block_update_equals_the_sequential_reference_update():
+    """apply_block (self-contained frames in bulk, the rest through the mirror) reaches exactly the state of the
+    reference's one-observation-at-a-time update in (frame, stream) order: node matrices bit for bit, per-frame
+    poses to 1e-12 (the bulk path sums the same votes in the same order, with batched inverses)."""
+    import contextlib
+    import io
+    from aprilslam_amd import dist as adist
+    rng = np.random.default_rng(42)
+    a, b = _new_slam(), _new_slam()
+    seq_counts = []
+    for obs in _blocks(rng, 2, 5, 7, 5):
+        world, n_frames, _ = obs.shape
+        pa, nseq = adist.apply_block(a, obs)
+        seq_counts.append(nseq)
+        order = [(s, f) for f in range(n_frames) for s in range(world)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            pb = adist._sequential(b, obs, order)
+        for (s, f), p in zip(order, pb):
+            assert np.isnan(pa[s, f]).all() if p is None else np.abs(pa[s, f] - p).max() < 1e-12
+        ga, gb = a.graph.get_nodes(), b.graph.get_nodes()
+        assert sorted(ga) == sorted(gb) and a.coordinate_id == b.coordinate_id
+        for k in ga:
+            assert np.array_equal(ga[k].local, gb[k].local) and np.array_equal(ga[k].world, gb[k].world)
+            assert (ga[k].reference, ga[k].weight, ga[k].updated, ga[k].visible) == (gb[k].reference, gb[k].weight, gb[k].updated, gb[k].visible)
+        assert np.array_equal(a.graph.estimated_pose, b.graph.estimated_pose) and a.visible_tags == b.visible_tags
+    # block 0 starts without a world tag, blocks 2 and 3 hold a frame that is not self-contained; 1 and 4 run in bulk
+    assert seq_counts[1] == 0 and seq_counts[4] == 0 and seq_counts[0] > 0 and seq_counts[2] > 0 and seq_counts[3] > 0
+
+
+def test_all_gather_and_ordered_update_two_ranks():
+    from aprilslam_amd import dist as adist
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g0 = out[0].reshape(-1).view(adist.OBS_DTYPE).reshape(out[0].shape[:-1])
+    g1 = out[1].reshape(-1).view(adist.OBS_DTYPE).reshape(out[1].shape[:-1])
+    assert g0.shape == (2, 3, 6)
+    assert np.array_equal(out[0], out[1]), "ranks disagree on the gathered observations"
+    # the gathered block equals what each rank packed locally
+    for r in range(world):
+        dets, poses, npf = _fake_step(r)
+        assert np.array_equal(g0[r], adist.pack_observations(dets, poses, npf, max_tags=6))
+    assert g0["id"][0, 0, :4].tolist() == [0, 1, 2, 3] and g0["id"][0, 1, 0] == -1 and g0["flags"][0, 0, 0] == 3
+
     res = []
-    for _ in range(2):  # identical input -> identical graph on "every rank"
-        slam = SLAM(Log(), {"camera_matrix": np.eye(3), "dist_coeffs": np.zeros(4)}, detector=object())
-        poses = adist.apply_observations(slam, g0)
-        res.append((poses, {k: (v.world.copy(), v.weight, v.reference) for k, v in slam.graph.get_nodes().items()}))
-    assert len(res[0][0]) == 6
-    for a, b in zip(res[0][0], res[1][0]):
-        assert (a is None and b is None) or np.array_equal(a, b)
-    assert res[0][1].keys() == res[1][1].keys()
+    for g in (g0, g1):  # identical input -> identical graph on "every rank"
+        slam = _new_slam()
+        poses, _ = adist.apply_block(slam, g)
+        res.append((poses, {k: (v.local.copy(), v.world.copy(), v.weight, v.reference) for k, v in slam.graph.get_nodes().items()}))
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 0
     for k in res[0][1]:
-        assert np.array_equal(res[0][1][k][0], res[1][1][k][0])
+        assert all(np.array_equal(x, y) for x, y in zip(res[0][1][k], res[1][1][k]))
 
 
 def test_shard_frames():

@@ -54,27 +54,71 @@ def test_random_scenes_end_to_end(family, decimate):
         det.close()
 
 
-def test_observation_gather_device_path(monkeypatch):
-    """The device path of all_gather_observations (cached device and page-locked buffers, asynchronous copies) with
-    the collective itself replaced by a local stand-in -- a one-GPU box cannot host two RCCL ranks.  The gloo tests
-    cover the real collective on CPU tensors."""
+def test_device_observation_records_and_graph_frames(family):
+    """asl_pack_observations_device against the host packing of the same results, and asl_graph_frames_device against
+    its numpy mirror (status and last-seen table exact, poses to 1e-9) on those records."""
     import torch
-    import torch.distributed as dist
     from aprilslam_amd import dist as adist
-
-    def fake_all_gather(outs, t):
-        for r, o in enumerate(outs):
-            o.copy_(t + r)
-
-    monkeypatch.setattr(dist, "is_initialized", lambda: True)
-    monkeypatch.setattr(dist, "get_world_size", lambda: 3)
-    monkeypatch.setattr(dist, "all_gather", fake_all_gather)
-    dev = torch.device("cuda", 0)
-    buf = adist.pinned_observation_buffer(16, 24)
-    rng = np.random.default_rng(5)
-    for it in range(3):  # second and third call reuse the cached buffers
-        buf[...] = rng.normal(size=buf.shape)
-        got = adist.all_gather_observations(buf, device=dev)
-        assert got.shape == (3,) + buf.shape
-        for r in range(3):
-            assert np.array_equal(got[r], buf + r)
+    det = _lib.Detector("tagStandard41h12", id_limit=0)
+    try:
+        w, h, nb, max_tags = 640, 360, 6, 8
+        frames = np.stack([_scene(w, h, 3 + b % 4, 500 + b, noise=0.0) for b in range(nb)])
+        frames[4] = 128  # a frame without detections
+        K = synth.camera_matrix(w, h)
+        dev = torch.device("cuda", 0)
+        t = torch.from_numpy(frames).to(dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        det.submit_device(t.data_ptr(), nb, 3, w, h, stream=st, K=K, dist=np.zeros(4), tag_size=10.0)
+        obs_dev = torch.empty((nb, max_tags, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        det.pack_observations_device(obs_dev.data_ptr(), max_tags, stream=st)
+        dets, poses, npf = det.collect()
+        host = adist.pack_observations(dets, poses, npf, max_tags)
+        got = obs_dev.cpu().numpy().reshape(-1).view(adist.OBS_DTYPE).reshape(nb, max_tags)
+        assert npf[4] == 0 and npf.sum() > 10
+        for name in ("id", "flags", "corners", "T"):
+            assert np.array_equal(got[name], host[name]), name
+        # two "streams": the block and a copy with one frame's world tag removed and one PnP marked failed
+        other = got.copy()
+        c = int(got["id"][0, 0])
+        other["id"][2, :-1] = got["id"][2, 1:]; other["flags"][2, :-1] = got["flags"][2, 1:]; other["T"][2, :-1] = got["T"][2, 1:]
+        other["flags"][3, 1] = 1
+        block = np.stack([got, other])
+        # frames whose lowest id is not c are "not self-contained" by definition: both implementations must agree on that
+        obs2 = torch.from_numpy(block.view(np.uint8).reshape(2, nb, max_tags, -1)).to(dev)
+        pose = torch.zeros((2 * nb, 16), dtype=torch.float64, device=dev)
+        status = torch.zeros(2 * nb, dtype=torch.uint8, device=dev)
+        last = torch.zeros(adist.MAX_IDS, dtype=torch.int32, device=dev)
+        picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        det.graph_frames_device(obs2.data_ptr(), 2, nb, max_tags, c, pose.data_ptr(), status.data_ptr(), last.data_ptr(), adist.MAX_IDS,
+                                picks_ptr=picks.data_ptr(), stream=st)
+        torch.cuda.synchronize(dev)
+        rp, rs, rl = adist.graph_frames_numpy(block, c)
+        assert np.array_equal(status.cpu().numpy().reshape(2, nb), rs)
+        assert np.array_equal(last.cpu().numpy().view(np.uint32), rl)
+        assert (rs == 0).sum() >= 3 and (rs == 1).sum() >= 2 and (rs == 2).sum() == 2
+        assert np.abs(pose.cpu().numpy().reshape(2, nb, 4, 4) - rp).max() < 1e-9
+        # the picks are the records the last-seen table points at, and they finish the update like the block itself does
+        pk = picks.cpu().numpy().reshape(-1).view(adist.OBS_DTYPE)
+        for t in np.nonzero(rl)[0]:
+            key = int(rl[t]) - 1
+            slot, o = key % max_tags, key // max_tags
+            assert pk[2 * t] == block[o % 2, o // 2, slot] and pk[2 * t + 1] == block[o % 2, o // 2, 0]
+        import golden_scene as G
+        a, b = G.new_slam(), G.new_slam()
+        good = block[:, [0, 1, 5]]  # frames that are self-contained in both streams
+        for sl in (a, b):
+            adist.apply_block(sl, good)  # first block: sequential (no world tag yet)
+        r2 = adist.graph_frames_numpy(good, c)
+        adist.apply_block(a, good, r2)
+        pk2 = np.zeros(2 * adist.MAX_IDS, dtype=adist.OBS_DTYPE)
+        for t in np.nonzero(r2[2])[0]:
+            key = int(r2[2][t]) - 1
+            pk2[2 * t] = good[(key // max_tags) % 2, (key // max_tags) // 2, key % max_tags]
+            pk2[2 * t + 1] = good[(key // max_tags) % 2, (key // max_tags) // 2, 0]
+        adist.apply_block(b, adist.ObsBlock(good), r2, picks=pk2, tail=good[:, -1])
+        for k_ in a.graph.get_nodes():
+            assert np.array_equal(a.graph.get_nodes()[k_].world, b.graph.get_nodes()[k_].world)
+            assert np.array_equal(a.graph.get_nodes()[k_].local, b.graph.get_nodes()[k_].local)
+        assert np.array_equal(a.graph.estimated_pose, b.graph.estimated_pose)
+    finally:
+        det.close()
