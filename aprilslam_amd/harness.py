@@ -11,7 +11,9 @@ per frame is small and is reproduced here without them:
 
 Ground truth and error metrics follow src/simulation/ground_truth.py:146-188 (camera pose in the world tag's
 frame, OpenGL->OpenCV flip diag(1,-1,-1)), :214-239 (ZYX Euler) and :274-300 (|dt|, Frobenius |dR|).
-The CSV has the reference's 17 columns in the reference's order, so src/analysis/* can read it unchanged.
+The three CSV files have the reference's names, columns and column order (data_logger.py:105-147: 17-column
+slam_simulation_data.csv, 22-column error_analysis.csv, 8-column covariance_analysis.csv; rows as
+simulation_engine.py:240-356 fills them), so src/analysis/* can read them unchanged.
 """
 import csv
 import json
@@ -27,12 +29,20 @@ MAIN_CSV_HEADER = ['Time', 'Number_of_Nodes', 'Average_Distance', 'Est_X', 'Est_
                    'Est_Yaw', 'GT_X', 'GT_Y', 'GT_Z', 'GT_Roll', 'GT_Pitch', 'GT_Yaw', 'Translation_Difference',
                    'Rotation_Difference']
 
+ERROR_CSV_HEADER = ['Number_of_Jumps', 'Est_X_Local', 'Est_Y_Local', 'Est_Z_Local', 'Est_Roll_Local', 'Est_Pitch_Local',
+                    'Est_Yaw_Local', 'Est_X_World', 'Est_Y_World', 'Est_Z_World', 'Est_Roll_World', 'Est_Pitch_World',
+                    'Est_Yaw_World', 'Tag_Est_X', 'Tag_Est_Y', 'Tag_Est_Z', 'Tag_Est_Roll', 'Tag_Est_Pitch', 'Tag_Est_Yaw',
+                    'Error_World', 'Error_Local', 'Translation_Error']
+COVARIANCE_CSV_HEADER = ['Number_of_Jumps', 'Tag_Est_X', 'Tag_Est_Y', 'Tag_Est_Z', 'Tag_Est_Roll', 'Tag_Est_Pitch', 'Tag_Est_Yaw',
+                         'Translation_Error']
+
 _FLIP = np.diag([1.0, -1.0, -1.0])
 
 
 def euler_to_rotation_matrix(euler_deg):
-    """[roll(x), pitch(y), yaw(z)] degrees -> Rz Ry Rx (ground_truth.py:241-272)."""
-    r, p, y = np.radians(np.asarray(euler_deg, dtype=np.float64))
+    """[roll(x), pitch(y), yaw(z)] degrees -> Rz Ry Rx (ground_truth.py:241-272).  Like the reference it computes in the
+    precision it is handed: the renderer's float32 tag rotations give a float32 matrix."""
+    r, p, y = np.radians(euler_deg)
     Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
     Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
     Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
@@ -57,23 +67,47 @@ class GroundTruth:
     """Analytic ground truth for a static-orientation camera, as the reference computes it."""
 
     def __init__(self, tags):
-        self.tags = {int(t["id"]): t for t in tags}
+        # the reference's renderer keeps tag positions and rotations as float32 (renderer.py:110-111)
+        self.tags = {int(t["id"]): {"position": np.array(t["position"], dtype=np.float32), "rotation": np.array(t["rotation"], dtype=np.float32)}
+                     for t in tags}
 
     def camera_to_tag(self, tag_id, camera_position):
+        """ground_truth.py:48-90"""
+        if tag_id not in self.tags:
+            raise ValueError(f"Tag {tag_id} not found in configuration")
         t = self.tags[tag_id]
-        rel = np.asarray(t["position"], dtype=np.float64) - np.asarray(camera_position, dtype=np.float64)
+        rel = t["position"] - np.asarray(camera_position)
         rel[1:] = -rel[1:]
         T = np.eye(4)
         T[:3, :3] = _FLIP @ euler_to_rotation_matrix(t["rotation"])
         T[:3, 3] = rel
         return T
 
+    def tag_world_transform(self, tag_id, camera_position, coordinate_frame_tag_id):
+        """ground_truth.py:92-114 (the product of the two camera<-tag transforms, as the reference forms it)"""
+        return self.camera_to_tag(tag_id, camera_position) @ self.camera_to_tag(coordinate_frame_tag_id, camera_position)
+
+    def tag_to_tag_distance(self, tag1_id, tag2_id, camera_position):
+        """ground_truth.py:116-144"""
+        if tag1_id not in self.tags or tag2_id not in self.tags:
+            raise ValueError(f"One or both tags not found: {tag1_id}, {tag2_id}")
+        cam = np.asarray(camera_position)
+        return np.linalg.norm((self.tags[tag1_id]["position"] - cam) - (self.tags[tag2_id]["position"] - cam))
+
     def inverse_transform(self, tag_id, camera_position):
-        """camera pose in tag `tag_id`'s frame (what SLAM.my_pose estimates when that tag is the world)."""
-        T = self.camera_to_tag(tag_id, camera_position)
+        """camera pose in tag `tag_id`'s frame (what SLAM.my_pose estimates when that tag is the world), ground_truth.py:146-188.
+        Same expressions on arrays of the same memory layout as the reference's (the product with a transposed view takes
+        its own path through BLAS), so the result is bit-identical."""
+        if tag_id not in self.tags:
+            raise ValueError(f"Tag {tag_id} not found in configuration")
+        t = self.tags[tag_id]
+        rel = t["position"] - np.asarray(camera_position)
+        rel[1:] = -rel[1:]
+        rotation = _FLIP @ euler_to_rotation_matrix(t["rotation"])
+        inverse_rotation = rotation.T
         out = np.eye(4)
-        out[:3, :3] = T[:3, :3].T
-        out[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+        out[:3, :3] = inverse_rotation
+        out[:3, 3] = -inverse_rotation @ rel
         return out
 
 
@@ -94,15 +128,20 @@ class HeadlessSimulation:
         params = {"camera_matrix": self.camera_matrix, "dist_coeffs": np.zeros((4, 1))}
         self.slam = slam if slam is not None else SLAM(logger, params, tag_size=self.tag_size_inner, device=device)
         self.ground_truth = GroundTruth(self.tags)
-        self.rows = []
+        self.rows, self.error_rows, self.covariance_rows = [], [], []
         self.start_time = time.time()
-        self._file = None
-        self._writer = None
+        self._files, self._writer, self._error_writer, self._covariance_writer = [], None, None, None
         if output_dir:
             os.makedirs(output_dir, exist_ok=True)
-            self._file = open(os.path.join(output_dir, "slam_simulation_data.csv"), "w", newline="")
-            self._writer = csv.writer(self._file)
-            self._writer.writerow(MAIN_CSV_HEADER)
+            writers = []
+            for name, header in (("slam_simulation_data.csv", MAIN_CSV_HEADER), ("error_analysis.csv", ERROR_CSV_HEADER),
+                                 ("covariance_analysis.csv", COVARIANCE_CSV_HEADER)):
+                f = open(os.path.join(output_dir, name), "w", newline="")
+                self._files.append(f)
+                w = csv.writer(f)
+                w.writerow(header)
+                writers.append(w)
+            self._writer, self._error_writer, self._covariance_writer = writers
 
     def step(self, camera_position, camera_rotation=(0.0, 0.0, 0.0)):
         """One iteration of the reference's main loop.  The reference's ground truth ignores camera rotation
@@ -124,7 +163,30 @@ class HeadlessSimulation:
         self.rows.append(row)
         if self._writer:
             self._writer.writerow(row)
+        self._log_node_analysis(camera_position)
         return {"pose": pose, "ground_truth": gt, "translation_error": dt, "rotation_error": dr, "ids": [d["id"] for d in detections]}
+
+    def _log_node_analysis(self, camera_position):
+        """One row per visible node in error_analysis.csv and covariance_analysis.csv (simulation_engine.py:302-356)."""
+        for tag_id, node in self.slam.graph.get_nodes().items():
+            if not node.visible:
+                continue
+            gt_local = self.ground_truth.camera_to_tag(tag_id, camera_position)
+            gt_world_distance = self.ground_truth.tag_to_tag_distance(tag_id, self.slam.coordinate_id, camera_position)
+            lt, le = node.local[:3, 3], rotation_matrix_to_euler(node.local[:3, :3])
+            wt, we = node.world[:3, 3], rotation_matrix_to_euler(node.world[:3, :3])
+            gtt, ge = gt_local[:3, 3], rotation_matrix_to_euler(gt_local[:3, :3])
+            local_error = abs(np.linalg.norm(lt) - np.linalg.norm(gtt))
+            world_error = abs(np.linalg.norm(wt) - gt_world_distance)
+            translation_error = np.linalg.norm(lt - gtt)
+            erow = [node.weight, lt[0], lt[1], lt[2], le[0], le[1], le[2], wt[0], wt[1], wt[2], we[0], we[1], we[2],
+                    gtt[0], gtt[1], gtt[2], ge[0], ge[1], ge[2], world_error, local_error, translation_error]
+            crow = [node.weight, lt[0], lt[1], lt[2], le[0], le[1], le[2], translation_error]  # the reference logs the LOCAL pose here
+            self.error_rows.append(erow)
+            self.covariance_rows.append(crow)
+            if self._error_writer:
+                self._error_writer.writerow(erow)
+                self._covariance_writer.writerow(crow)
 
     def statistics(self):
         """frames/s over logged frames (data_logger.py:266-286) plus error RMSE in units and, if known, mm."""
@@ -139,6 +201,6 @@ class HeadlessSimulation:
         return out
 
     def close(self):
-        if self._file:
-            self._file.close()
-            self._file = None
+        for f in self._files:
+            f.close()
+        self._files = []

@@ -1,7 +1,39 @@
+import json
+import os
+
 import numpy as np
 import pytest
 
 from aprilslam_amd import harness, synth
+
+FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ground_truth_fixtures.json")))
+
+
+def _h(v):
+    return np.array([float.fromhex(x) for x in v])
+
+
+def test_ground_truth_matches_the_references_own_code():
+    """harness.GroundTruth / Euler / error metrics against values produced by running the reference's
+    src/simulation/ground_truth.py (tests/golden/make_ground_truth_fixtures.py): bit for bit."""
+    gt = harness.GroundTruth(FIX["tags"])
+    for c in FIX["cases"]:
+        cam = _h(c["camera_position"])
+        for t in FIX["tags"]:
+            i = t["id"]
+            assert np.array_equal(gt.camera_to_tag(i, cam.copy()).ravel(), _h(c["camera_to_tag"][str(i)]))
+            assert np.array_equal(gt.inverse_transform(i, cam.copy()).ravel(), _h(c["inverse"][str(i)]))
+            assert float(gt.tag_to_tag_distance(i, 0, cam.copy())) == float.fromhex(c["tag_to_tag"][str(i)])
+            assert np.array_equal(gt.tag_world_transform(i, cam.copy(), 0).ravel(), _h(c["tag_world"][str(i)]))
+    for e in FIX["euler"]:
+        R = harness.euler_to_rotation_matrix(_h(e["euler_deg"]))
+        assert np.array_equal(R.ravel(), _h(e["R"]))
+        assert np.array_equal(harness.rotation_matrix_to_euler(R), _h(e["back"]))
+    for e in FIX["pose_errors"]:
+        dt, dr = harness.calculate_pose_error(_h(e["estimated"]).reshape(4, 4), _h(e["ground_truth"]).reshape(4, 4))
+        assert dt == float.fromhex(e["translation"]) and dr == float.fromhex(e["rotation"])
+    with pytest.raises(ValueError):
+        gt.camera_to_tag(99, np.zeros(3))
 
 
 def test_ground_truth_matches_renderer_model():
@@ -25,11 +57,38 @@ def test_euler_and_error_metrics():
     assert harness.calculate_pose_error(A, B) == (5.0, 0.0)
 
 
-def test_csv_header_is_the_references():
-    # column names of the reference's main CSV (data_logger.py:110-117): a data format, kept verbatim
-    assert len(harness.MAIN_CSV_HEADER) == 17
+def test_csv_headers_are_the_references():
+    # column names of the reference's three CSV files (data_logger.py:110-147): a data format, kept verbatim
+    assert len(harness.MAIN_CSV_HEADER) == 17 and len(harness.ERROR_CSV_HEADER) == 22 and len(harness.COVARIANCE_CSV_HEADER) == 8
     assert harness.MAIN_CSV_HEADER[:3] == ['Time', 'Number_of_Nodes', 'Average_Distance']
     assert harness.MAIN_CSV_HEADER[-2:] == ['Translation_Difference', 'Rotation_Difference']
+    assert harness.ERROR_CSV_HEADER[0] == 'Number_of_Jumps' and harness.ERROR_CSV_HEADER[-3:] == ['Error_World', 'Error_Local', 'Translation_Error']
+    assert harness.COVARIANCE_CSV_HEADER == ['Number_of_Jumps', 'Tag_Est_X', 'Tag_Est_Y', 'Tag_Est_Z', 'Tag_Est_Roll', 'Tag_Est_Pitch',
+                                             'Tag_Est_Yaw', 'Translation_Error']
+
+
+def test_node_analysis_rows_without_a_gpu(tmp_path):
+    """The 22- and 8-column rows (simulation_engine.py:302-356) from a SLAM object fed with exact poses: the two distance
+    errors are zero (Translation_Error compares inv(T) with T, as the reference does, and is not), and the files hold one
+    row per visible node per frame."""
+    import csv
+    import logging
+    import golden_scene as G
+    sc = synth.default_scene()
+    slam = G.new_slam()
+    sim = harness.HeadlessSimulation(sc, logging, output_dir=str(tmp_path), slam=slam)
+    cam = np.array([1.0, -2.0, 3.0])
+    ids = [0, 1, 2]
+    T = np.stack([sim.ground_truth.camera_to_tag(i, cam) for i in ids])
+    G.feed(slam, ids, T)
+    sim._log_node_analysis(cam)
+    sim.close()
+    erows = list(csv.reader(open(tmp_path / "error_analysis.csv")))
+    crows = list(csv.reader(open(tmp_path / "covariance_analysis.csv")))
+    assert erows[0] == harness.ERROR_CSV_HEADER and crows[0] == harness.COVARIANCE_CSV_HEADER
+    assert len(erows) == 4 and len(crows) == 4 and all(len(r) == 22 for r in erows) and all(len(r) == 8 for r in crows)
+    for r in erows[1:]:
+        assert abs(float(r[-2])) < 1e-9 and abs(float(r[-3])) < 1e-9 and float(r[0]) == 1
 
 
 @pytest.mark.gpu
@@ -47,3 +106,6 @@ def test_headless_run_default_scene(tmp_path):
     assert st["frames"] == 6 and st["translation_rmse_units"] < 1.8 and st["rotation_fro_rmse"] < 0.05
     rows = list(csv.reader(open(tmp_path / "slam_simulation_data.csv")))
     assert rows[0] == harness.MAIN_CSV_HEADER and len(rows) == 7 and len(rows[1]) == 17
+    erows = list(csv.reader(open(tmp_path / "error_analysis.csv")))
+    crows = list(csv.reader(open(tmp_path / "covariance_analysis.csv")))
+    assert len(erows) == len(crows) >= 1 + 6 * 2 and len(erows[1]) == 22 and len(crows[1]) == 8
