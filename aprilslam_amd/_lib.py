@@ -27,6 +27,8 @@ class AslDebugQuad(C.Structure):
     _fields_ = [("p", (C.c_double * 2) * 4), ("cluster", C.c_uint64), ("frame", C.c_int32), ("reversed_border", C.c_int32)]
 
 
+PLANE_DTYPE = np.dtype([("Hi", "<f8", (9,)), ("bbox", "<i4", (4,)), ("tex", "<i4"), ("pad", "<i4")])  # asl_render_plane
+assert PLANE_DTYPE.itemsize == 96
 OBS_DTYPE = np.dtype([("id", "<i4"), ("flags", "<i4"), ("corners", "<f4", (8,)), ("T", "<f8", (12,))])  # asl_obs
 assert OBS_DTYPE.itemsize == 136
 DET_DTYPE = np.dtype([("id", "<i4"), ("hamming", "<i4"), ("margin", "<f4"), ("frame", "<i4"),
@@ -39,7 +41,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_render_frames_device",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -81,6 +83,7 @@ def load():
     L.asl_solve_pnp_batch.argtypes = [vp, C.POINTER(C.c_float), dp, dp, i32, C.c_double, dp, dp, dp, u8p, i32]
     L.asl_gn_solve.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_double, i32,
                                dp, dp, i32, dp]
+    L.asl_render_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, i32, vp, i32, i32, C.c_double, dp, dp, i32, vp]
     L.asl_pack_observations_device.argtypes = [vp, vp, i32, vp]
     L.asl_graph_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
     L.asl_debug_fetch.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -225,6 +228,23 @@ class Detector:
         check(self._L.asl_submit_batch_device(self._h, C.c_void_p(int(data_ptr)), n_frames, channels, width, height, stride,
                                               frame_pitch, C.c_void_p(int(stream)), Kp, dpp, nd, float(tag_size)))
         self._inflight = (n_frames, K is not None)
+
+    def render_frames_device(self, frames_ptr, n_frames, width, height, planes_ptr, max_planes, textures_ptr, tw, th, half, K=None, dist=None,
+                             stride=None, frame_pitch=None, stream=0):
+        """asl_render_frames_device: BGR frames straight into device memory (frames_ptr, planes_ptr, textures_ptr are device
+        addresses; K / dist are host arrays, only for a camera with lens distortion)."""
+        stride = stride or 3 * width
+        frame_pitch = frame_pitch or stride * height
+        dp = C.POINTER(C.c_double)
+        Kp = dpp = None
+        nd = 0
+        if dist is not None:
+            Kc = np.ascontiguousarray(K, dtype=np.float64)
+            dc = np.ascontiguousarray(dist, dtype=np.float64).ravel()
+            Kp, dpp, nd = Kc.ctypes.data_as(dp), dc.ctypes.data_as(dp), len(dc)
+        check(self._L.asl_render_frames_device(self._h, C.c_void_p(int(frames_ptr)), int(n_frames), int(width), int(height), int(stride),
+                                               int(frame_pitch), C.c_void_p(int(planes_ptr)), int(max_planes), C.c_void_p(int(textures_ptr)),
+                                               int(tw), int(th), float(half), Kp, dpp, nd, C.c_void_p(int(stream))))
 
     def pack_observations_device(self, out_ptr, max_tags, stream=0):
         """asl_pack_observations_device: the submitted batch's results as n_frames x max_tags asl_obs records at the

@@ -24,6 +24,7 @@
 #include "k_pnp.inc"
 #include "k_dedup.inc"
 #include "k_graph.inc"
+#include "k_render.inc"
 #include "k_gn.inc"
 
 static thread_local std::string g_err;
@@ -661,6 +662,31 @@ extern "C" int asl_detect_bgr_u8(asl_detector *d, const uint8_t *bgr, int w, int
 {
     const uint8_t *fr[1] = {bgr};
     return asl_detect_batch_u8(d, fr, 1, 3, w, h, stride, out, max_out, nullptr, n_out);
+}
+
+extern "C" int asl_render_frames_device(asl_detector *d, void *d_frames, int n_frames, int w, int h, int stride, size_t frame_pitch,
+                                        const void *d_planes, int max_planes, const void *d_textures, int tw, int th, double half,
+                                        const double *K, const double *dist, int n_dist, void *stream)
+{
+    if (!d || !d_frames || !d_planes || !d_textures) return fail(ASL_EINVAL, "NULL argument");
+    if (n_frames <= 0 || w <= 0 || h <= 0 || max_planes <= 0 || tw <= 0 || th <= 0) return fail(ASL_EINVAL, "sizes must be positive");
+    if (stride < 3 * w || frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "stride / frame_pitch smaller than a BGR row / frame");
+    if (dist && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 4 or 5");
+    if (dist && !K) return fail(ASL_EINVAL, "lens coefficients need the camera matrix");
+    static_assert(sizeof(RenderPlane) == sizeof(asl_render_plane) && sizeof(asl_render_plane) == 96, "asl_render_plane layout");
+    HIPCHK(hipSetDevice(d->device));
+    RenderCam cam;
+    memset(&cam, 0, sizeof cam);
+    cam.iters = 8;
+    if (K && dist) {
+        cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+        cam.k1 = dist[0]; cam.k2 = dist[1]; cam.p1 = dist[2]; cam.p2 = dist[3]; cam.k3 = n_dist >= 5 ? dist[4] : 0.0;
+        cam.distort = 1;
+    }
+    hipLaunchKernelGGL(k_render, dim3((w + 63) / 64, (h + 3) / 4, (unsigned int)n_frames), dim3(64, 4), 0, (hipStream_t)stream, (uint8_t *)d_frames, w, h,
+                       stride, frame_pitch, (const RenderPlane *)d_planes, max_planes, (const uint8_t *)d_textures, tw, th, half, cam);
+    HIPCHK(hipGetLastError());
+    return ASL_OK;
 }
 
 extern "C" int asl_pack_observations_device(asl_detector *d, void *d_obs, int max_tags, void *stream)

@@ -91,51 +91,94 @@ def _bilinear(tex, u, v):
     return out
 
 
-def render_frame(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), cam_rotation_deg=(0, 0, 0),
-                 fov_y_deg=45.0, family="tagStandard41h12", cell_px=40, noise_sigma=0.0, rng=None, textures=None):
-    """Render one H x W x 3 BGR uint8 frame.
+UNDISTORT_ITERS = 8  # fixed-point iterations of the per-pixel inverse lens distortion (renderer side)
 
-    tags: iterable of dicts {"id", "position" [x,y,z], "rotation" [pitch,yaw,roll] deg} (the
-    reference's sim_settings.json schema).  Returns (frame, gt) with gt[id] = camera<-tag 4x4.
-    """
-    fam = get_family(family)
+
+def undistort_normalized(xd, yd, dist):
+    """Inverse of the Brown-Conrady model (k1, k2, p1, p2, k3) on normalised image coordinates by fixed-point iteration
+    (the scheme cv2.undistortPoints uses), UNDISTORT_ITERS steps.  Works on arrays."""
+    k1, k2, p1, p2, k3 = (list(np.asarray(dist, dtype=np.float64).ravel()) + [0.0] * 5)[:5]
+    x, y = xd, yd
+    for _ in range(UNDISTORT_ITERS):
+        r2 = x * x + y * y
+        icdist = 1 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (xd - dx) * icdist
+        y = (yd - dy) * icdist
+    return x, y
+
+
+def frame_geometry(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), cam_rotation_deg=(0, 0, 0), fov_y_deg=45.0,
+                   dist=None):
+    """What a renderer needs for one frame: per visible tag (painter's order, far to near) the inverse of the plane
+    homography -- pixel -> tag plane without `dist`, normalised image coordinates -> tag plane with it -- and the pixel
+    bounding box of the tag.  Returns (planes, gt): planes = list of dicts {"id", "Hi" 3x3, "bbox" (x0, x1, y0, y1)},
+    gt[id] = camera<-tag 4x4."""
     K = camera_matrix(width, height, fov_y_deg)
-    frame = np.empty((height, width, 3), dtype=np.uint8)
-    frame[:] = (128, 0, 128)  # BGR of RGB (128, 0, 128)
     half = 0.5 * tag_size_outer
-    gt = {}
-    order = []
+    gt, order = {}, []
     for tag in tags:
         T = camera_from_tag(tag["position"], tag["rotation"], cam_position, cam_rotation_deg)
         gt[int(tag["id"])] = T
         order.append((T[2, 3], tag, T))
     order.sort(key=lambda e: -e[0])  # far to near
+    planes = []
     for _, tag, T in order:
-        # homography tag plane (X, Y, 1) -> pixel
-        Hm = K @ np.column_stack([T[:3, 0], T[:3, 1], T[:3, 3]])
+        Hn = np.column_stack([T[:3, 0], T[:3, 1], T[:3, 3]])
+        Hm = K @ Hn  # homography tag plane (X, Y, 1) -> pixel
         corners = np.array([[-half, -half, 1], [half, -half, 1], [half, half, 1], [-half, half, 1]]).T
         pc = Hm @ corners
         if np.any(pc[2] <= 1e-9):
             continue  # crosses the camera plane: skip (never happens in the generated scenes)
         px = pc[0] / pc[2]
         py = pc[1] / pc[2]
-        x0 = max(int(np.floor(px.min())), 0)
-        x1 = min(int(np.ceil(px.max())) + 1, width)
-        y0 = max(int(np.floor(py.min())), 0)
-        y1 = min(int(np.ceil(py.max())) + 1, height)
+        pad = 0
+        if dist is not None:
+            # the bounding box is that of the undistorted projection: leave room for the lens to move the outline
+            pad = 2 + int(0.08 * max(width, height))
+        x0 = max(int(np.floor(px.min())) - pad, 0)
+        x1 = min(int(np.ceil(px.max())) + 1 + pad, width)
+        y0 = max(int(np.floor(py.min())) - pad, 0)
+        y1 = min(int(np.ceil(py.max())) + 1 + pad, height)
         if x0 >= x1 or y0 >= y1:
             continue
-        Hi = np.linalg.inv(Hm)
+        planes.append({"id": int(tag["id"]), "Hi": np.linalg.inv(Hm if dist is None else Hn), "bbox": (x0, x1, y0, y1)})
+    return planes, gt
+
+
+def render_frame(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), cam_rotation_deg=(0, 0, 0),
+                 fov_y_deg=45.0, family="tagStandard41h12", cell_px=40, noise_sigma=0.0, rng=None, textures=None, dist=None):
+    """Render one H x W x 3 BGR uint8 frame.
+
+    tags: iterable of dicts {"id", "position" [x,y,z], "rotation" [pitch,yaw,roll] deg} (the
+    reference's sim_settings.json schema).  Returns (frame, gt) with gt[id] = camera<-tag 4x4.
+    dist = (k1, k2, p1, p2[, k3]): the frame a camera with that lens distortion would deliver (the reference's second
+    caller, a calibrated webcam: video_detection.py:209-296, calibrate.py:71-75); None = the simulator's ideal pinhole.
+    """
+    fam = get_family(family)
+    K = camera_matrix(width, height, fov_y_deg)
+    frame = np.empty((height, width, 3), dtype=np.uint8)
+    frame[:] = (128, 0, 128)  # BGR of RGB (128, 0, 128)
+    half = 0.5 * tag_size_outer
+    planes, gt = frame_geometry(width, height, tags, tag_size_outer, cam_position, cam_rotation_deg, fov_y_deg, dist)
+    for pl in planes:
+        x0, x1, y0, y1 = pl["bbox"]
+        Hi = pl["Hi"]
         xs, ys = np.meshgrid(np.arange(x0, x1) + 0.5, np.arange(y0, y1) + 0.5)
+        if dist is not None:
+            xs, ys = undistort_normalized((xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], dist)
         q0 = Hi[0, 0] * xs + Hi[0, 1] * ys + Hi[0, 2]
         q1 = Hi[1, 0] * xs + Hi[1, 1] * ys + Hi[1, 2]
         q2 = Hi[2, 0] * xs + Hi[2, 1] * ys + Hi[2, 2]
         X = q0 / q2
         Y = q1 / q2
         inside = (X >= -half) & (X <= half) & (Y >= -half) & (Y <= half)
+        if dist is not None:
+            inside &= q2 > 0
         if not inside.any():
             continue
-        tex = textures[int(tag["id"])] if textures is not None else fam.texture(int(tag["id"]), cell_px)
+        tex = textures[pl["id"]] if textures is not None else fam.texture(pl["id"], cell_px)
         th, tw = tex.shape[:2]
         u = (X + half) / (2 * half) * tw
         v = (1.0 - (Y + half) / (2 * half)) * th  # image row 0 is the top (t = 1)
@@ -146,6 +189,37 @@ def render_frame(width, height, tags, tag_size_outer, cam_position=(0, 0, 0), ca
         rng = rng or np.random.default_rng(0)
         frame = np.clip(frame.astype(np.float64) + rng.normal(0, noise_sigma, frame.shape), 0, 255).astype(np.uint8)
     return frame, gt
+
+
+def render_planes(width, height, tags, tag_size_outer, cameras, fov_y_deg=45.0, dist=None, tex_index=None):
+    """The per-frame plane lists asl_render_frames_device consumes, for a list of cameras [(position, rotation_deg), ...]:
+    (planes (n_frames, max_planes) array of _lib.PLANE_DTYPE, gts list of {id: camera<-tag}).  tex_index maps a tag id to
+    its texture (default: the id itself)."""
+    from ._lib import PLANE_DTYPE
+    max_planes = max(1, len(tags))
+    planes = np.zeros((len(cameras), max_planes), dtype=PLANE_DTYPE)
+    planes["tex"] = -1
+    gts = []
+    for f, (pos, rot) in enumerate(cameras):
+        pls, gt = frame_geometry(width, height, tags, tag_size_outer, pos, rot, fov_y_deg, dist)
+        gts.append(gt)
+        for k, pl in enumerate(pls):
+            planes["Hi"][f, k] = pl["Hi"].ravel()
+            planes["bbox"][f, k] = pl["bbox"]
+            planes["tex"][f, k] = pl["id"] if tex_index is None else tex_index[pl["id"]]
+    return planes, gts
+
+
+def gray_textures(ids, family="tagStandard41h12", cell_px=40, textures=None):
+    """(n, th, tw) uint8 stack of the tag textures for ids 0..max(ids) (rows top to bottom), as the device renderer wants them."""
+    fam = get_family(family)
+    n = max(ids) + 1
+    first = textures[ids[0]] if textures is not None else fam.texture(ids[0], cell_px)
+    out = np.zeros((n,) + first.shape[:2], dtype=np.uint8)
+    for i in ids:
+        t = textures[i] if textures is not None else fam.texture(i, cell_px)
+        out[i] = t[:, :, 0]
+    return out
 
 
 def default_scene():

@@ -167,6 +167,26 @@ int asl_pack_observations_device(asl_detector *det, void *d_obs, int max_tags, v
 int asl_graph_frames_device(asl_detector *det, const void *d_obs, int world, int n_frames, int max_tags, int coordinate_id,
                             double *d_pose, uint8_t *d_status, uint32_t *d_last, int n_ids, void *d_picks, void *stream);
 
+/* ---- before the detector: the image-formation step on the device (reference src/simulation/renderer.py:197-274:
+   purple clear colour, one GL_LINEAR-textured quad per tag, BGR read-back).  One plane per visible tag and frame, in
+   painter's order (far to near); a plane with tex < 0 ends a frame's list. */
+typedef struct {
+    double Hi[9];     /* row-major 3x3: pixel centre (x+0.5, y+0.5, 1) -> tag plane (X, Y, w); with lens coefficients it maps
+                         UNDISTORTED NORMALISED image coordinates instead */
+    int32_t bbox[4];  /* x0, x1, y0, y1: pixels outside [x0,x1) x [y0,y1) cannot hit the tag */
+    int32_t tex;      /* index into d_textures */
+    int32_t pad;
+} asl_render_plane;   /* 96 bytes */
+
+/* Renders n_frames BGR frames of w x h pixels into device memory.  d_planes: n_frames x max_planes asl_render_plane (device);
+   d_textures: n_tex gray textures of tw x th bytes, rows top to bottom (device); half = half the side of the textured quad
+   in scene units.  K (9 doubles) and dist (n_dist = 4 or 5) are host pointers and only needed for a camera with lens
+   distortion (the reference's webcam caller, src/detection/video_detection.py:209-296); pass K = NULL for the
+   simulator's pinhole. */
+int asl_render_frames_device(asl_detector *det, void *d_frames, int n_frames, int w, int h, int stride, size_t frame_pitch,
+                             const void *d_planes, int max_planes, const void *d_textures, int tw, int th, double half,
+                             const double *K, const double *dist, int n_dist, void *stream);
+
 /* Introspection for the parity tests: copy an intermediate buffer of the LAST batch to host.
    what: 0 = decimated gray (u8, B*sh*sw)     1 = threshold image (u8, B*sh*sw)
          2 = component labels (u32, B*sh*sw)  3 = component sizes by label (u32, B*sh*sw)
