@@ -317,7 +317,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
 static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
 {
     dim3 blk(64, 4, 1);
-    int thx = (g.sh + TILESZ - 1) / TILESZ;
+    int thx = (g.sh + TILESZ - 1) / TILESZ;  // generic decimation kernel: tile rows
     unsigned int B = (unsigned int)g.nframes;
     d->nev = 0;
     STAGE("memset");

@@ -48,17 +48,49 @@ def make_frames(n_distinct, seed=20250620 + 1, with_gt=False, phase=0.0):
     return np.stack(frames)
 
 
-def algorithmic_bytes(kernel, w, h, ch, f):
-    """Compulsory HBM bytes of one launch PER FRAME (reads + writes of the kernel's operands,
-    each counted once).  DESIGN.md section 'Kernels' derives these."""
+def camera_trajectory(n, phase=0.0):
+    """n camera poses (position, rotation in degrees) along a smooth closed curve"""
+    cams = []
+    for i in range(n):
+        a = 2 * np.pi * i / max(n, 1) + phase
+        cams.append(((1.5 * np.cos(a), 1.0 * np.sin(a), 2.0 * np.sin(2 * a)), (0.6 * np.sin(a), 0.8 * np.cos(a), 0.5 * np.sin(3 * a))))
+    return cams
+
+
+def render_stream_device(det, n_frames, dev, phase=0.0, seed=20250620 + 1):
+    """n_frames DISTINCT frames of the seeded 20-tag scene, rendered on the device (asl_render_frames_device: the
+    reference renderer's image formation as a kernel, byte-identical to aprilslam_amd.synth.render_frame) straight into
+    HBM.  Returns (uint8 tensor (n_frames, H, W, 3), per-frame ground truth {id: camera<-tag})."""
+    import torch
+    from aprilslam_amd import synth
+    rng = np.random.default_rng(seed)
+    tags = synth.random_scene(W, H, NTAGS, rng, tag_size_outer=TAG_OUTER)
+    cams = camera_trajectory(n_frames, phase)
+    planes, gts = synth.render_planes(W, H, tags, TAG_OUTER, cams)
+    tex = synth.gray_textures([int(t["id"]) for t in tags])
+    d_tex = torch.from_numpy(tex).to(dev)
+    d_planes = torch.from_numpy(planes.view(np.uint8).reshape(planes.shape + (-1,))).to(dev)
+    out = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, device=dev)
+    det.render_frames_device(out.data_ptr(), n_frames, W, H, d_planes.data_ptr(), planes.shape[1], d_tex.data_ptr(), tex.shape[2], tex.shape[1],
+                             0.5 * TAG_OUTER, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    return out, gts
+
+
+def algorithmic_bytes(kernel, w, h, ch, f, runs=7200, points=18600):
+    """Compulsory HBM bytes of one launch PER FRAME (reads + writes of the kernel's operands, each counted once).
+    DESIGN.md section 'Kernels' derives these.  `runs` / `points` = runs of one colour inside a 64-pixel word and staged
+    boundary points of the bench scene (per frame)."""
     sw, sh = 1 + (w - 1) // f, 1 + (h - 1) // f
     npix = sw * sh
     ntile = (sw // 4) * (sh // 4)
-    full = w * h * ch
+    rows_read = sh * w * ch  # only every f-th row of the input is touched (whole rows: 64-byte lines)
     table = {
-        "k_decimate_minmax": full + npix + 2 * ntile,
-        "k_cc_tile": npix + 2 * ntile + npix + 4 * npix + 4 * npix,
-        "k_cluster_count": npix + 4 * npix + 4 * npix,
+        "k_decimate_minmax": rows_read + npix + 2 * ntile,
+        "k_tile_cut": 2 * ntile + ntile,
+        "k_seg_tile": npix + ntile + 2 * npix // 8 + npix // 8 + 4 * runs,              # gray + cuts in; two bit masks + root mask + run labels out
+        "k_seg_points": 2 * npix // 8 + 12 * runs + 12 * points,                        # masks + (label, root, size) per run in; 12 B per staged point out
+        "k_point_place": 12 * points + 8 * points,
     }
     return table.get(kernel)
 
@@ -163,13 +195,73 @@ def spawn_ranks(n, argv):
     return max(abs(c) for c in rc)
 
 
+def _cpu_worker(args):
+    frames, K, budget = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from aprilslam_amd.families import get_family
+    fam = get_family()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        dets = O.detect_bgr(frames[n % len(frames)], fam)
+        if dets:
+            O.solve_pnp(np.stack([d["corners"] for d in dets]), K, np.zeros(4), TAG_INNER)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(frames, K, budget_s=10.0):
+    """The CPU restatement on every host core at once, frame-parallel (one process per core, each its own frames)."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))  # the cores this process may use, not the ones the machine has
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ctx = mp.get_context("spawn")  # fresh interpreters: no forked HIP state
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(frames[i % len(frames):] if len(frames) > 1 else frames, K, budget_s) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    rate = sum(r[0] / r[1] for r in res)
+    return {"value": rate, "unit": "frames/s", "cores": cores, "cpu": model, "kind": "port",
+            "sample": "%d frames in %.1f s wall (%d processes x %.0f s of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp)" % (total, wall, cores, budget_s)}
+
+
+def h2d_included(det, d_frames, K, n=256, reps=3):
+    """frames/s when the frames start in (page-locked) HOST memory: asl_detect_batch_pose_u8 copies them over PCIe, then
+    runs the same batch.  Reported next to `value`, never as `value`."""
+    import torch
+    n = min(n, d_frames.shape[0])
+    host = d_frames[:n].cpu().pin_memory()
+    a = host.numpy()
+    det.detect_host(a, K=K, dist=np.zeros(4), tag_size=TAG_INNER)  # staging buffer allocation
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_host(a, K=K, dist=np.zeros(4), tag_size=TAG_INNER)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n / dt, "unit": "frames/s", "frames_per_call": n, "ms_per_call": 1e3 * dt,
+            "host_to_device_GBs": n * W * H * 3 / dt / 1e9,
+            "note": "asl_detect_batch_pose_u8 from page-locked host frames: PCIe copy + the same batch, synchronous"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
-    ap.add_argument("--distinct", type=int, default=32, help="distinct rendered frames (tiled to --batch)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (tiled to --batch); 0 = every frame of the batch is distinct")
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
@@ -205,11 +297,16 @@ def main():
     from aprilslam_amd import dist as adist
 
     K = synth.camera_matrix(W, H)
-    distinct, distinct_gt = make_frames(args.distinct, with_gt=True, phase=2 * np.pi * rank / max(world, 1) / max(args.distinct, 1) * 0.5)  # each rank = its own camera, one scene
     xchg = world > 1 or args.exchange  # the part of a step that needs every rank
     B = args.batch
-    reps = (B + len(distinct) - 1) // len(distinct)
-    d_frames = torch.from_numpy(distinct).to(dev).repeat(reps, 1, 1, 1)[:B].contiguous()
+    ndist = B if args.distinct <= 0 else min(args.distinct, B)
+    # every rank = its own camera on the trajectory, one scene: the streams see the same tags from different places
+    render_det = _lib.Detector("tagStandard41h12", device=local_rank, id_limit=0)
+    d_distinct, distinct_gt = render_stream_device(render_det, ndist, dev, phase=np.pi * rank / max(world, 1) / max(ndist, 1))
+    render_det.close()
+    d_frames = d_distinct if ndist == B else d_distinct.repeat((B + ndist - 1) // ndist, 1, 1, 1)[:B].contiguous()
+    NCHK = min(32, ndist)  # frames checked against ground truth / handed to the CPU baseline
+    distinct = d_distinct[:NCHK].cpu().numpy()
     # P detector workspaces used round-robin: batch i is submitted before batch i-1 is collected, so the host
     # post-processing (dedup/sort/copy-out) and the latency-bound tail kernels of one batch overlap the bulk
     # kernels of the next.  P = 1 is the plain synchronous call.
@@ -388,12 +485,19 @@ def main():
                     "avg_launch_ms_isolated": isolated.get(dom), "algorithmic_bytes_per_frame": pts * 9}
         # HBM traffic of the dominant kernel: not measurable live; taken from the committed rocprofv3 --pmc pass
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             if tr.get("batch_frames") == B and dom in tr["bytes_per_launch"]:
                 roof["traffic"] = tr["bytes_per_launch"][dom]
                 roof["traffic_source"] = tr["source"]
         except Exception:
             pass
+        line_rooflines = []
+        for kname, ms_ in sorted(kernels_only.items(), key=lambda kv: -kv[1]):
+            ab_ = algorithmic_bytes(kname, W, H, 3, 2)
+            if ab_ is not None:
+                gbs = ab_ * B / (ms_ * 1e-3) / 1e9
+                line_rooflines.append({"kernel": kname, "avg_launch_ms": ms_, "avg_launch_ms_isolated": isolated.get(kname),
+                                       "algorithmic_bytes_per_frame": ab_, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS})
         seg_names = ("memset", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border_cols", "k_seg_border_rows", "k_seg_roots",
                                              "k_hash_clear", "k_seg_points", "k_cluster_filter", "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
@@ -404,7 +508,7 @@ def main():
             "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/f64",
-            "data": "synthetic: %d distinct rendered frames of a seeded 20-tag scene tiled to %d frames per step, resident in HBM" % (len(distinct), B),
+            "data": "synthetic: %d distinct frames of a seeded 20-tag scene along a camera trajectory, rendered on the device into HBM (%d frames per step)" % (ndist, B),
             "config": {"workload": "configs[1]: 1280x720 BGR stream, 20 tags/frame, detect + PnP", "batch_frames": B,
                        "decimate": 2, "tags_found_per_batch": n_found, "pipeline_parts": P, "parallelism": "1 video stream per GPU"},
             "multi_gpu": None if not xchg else {
@@ -418,13 +522,17 @@ def main():
             "roofline": roof,
             "stage_threshold_segmentation": {"ms_per_batch_isolated": seg, "algorithmic_read_bytes_per_frame": seg_bytes,
                                              "achieved_GBs": seg_gbs, "frac_of_hbm_peak": seg_gbs / HBM_PEAK_GBS},
+            "kernel_rooflines_hbm": line_rooflines,
             "kernel_ms_per_batch": avg,
             "kernel_ms_per_batch_isolated": isolated,
         }
-        nchk = min(B, len(distinct))
+        nchk = NCHK
         line["pose_rmse"] = pose_rmse_vs_ground_truth(last[0], last[1], last[2], distinct_gt[:nchk])
+        if world == 1:
+            line["h2d_included"] = h2d_included(detectors[0], d_frames, K)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(distinct[:nchk], K)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
