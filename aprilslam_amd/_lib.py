@@ -40,7 +40,7 @@ assert POSE_DTYPE.itemsize == C.sizeof(AslPose)
 assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
-    "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_last_error", "asl_version", "asl_detect_gray_u8",
+    "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_detector_set_pnp_both_minima", "asl_last_error", "asl_version", "asl_detect_gray_u8",
     "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_render_frames_device",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
@@ -71,6 +71,7 @@ def load():
     L.asl_detector_destroy.argtypes = [vp]
     L.asl_detector_destroy.restype = None
     L.asl_detector_set_id_limit.argtypes = [vp, i32]
+    L.asl_detector_set_pnp_both_minima.argtypes = [vp, i32]
     L.asl_detect_gray_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_bgr_u8.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.asl_detect_batch_u8.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -113,6 +114,10 @@ class Detector:
         self.device = int(device)
         if id_limit is not None:
             check(L.asl_detector_set_id_limit(self._h, int(id_limit)))
+
+    def set_pnp_both_minima(self, enabled):
+        """asl_detector_set_pnp_both_minima: off = the reference's (cv2's) single minimum, on = the better of the two planar poses"""
+        check(self._L.asl_detector_set_pnp_both_minima(self._h, 1 if enabled else 0))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -53,6 +53,7 @@ struct asl_detector {
     int maxhamming = 1;
     int decimate = 2;
     int refine = 1;
+    int pnp_both_minima = 0;
     FamilyDev fam;
     unsigned long long *d_codes = nullptr;
 
@@ -196,6 +197,13 @@ extern "C" int asl_detector_set_id_limit(asl_detector *d, int n_ids)
     if (n_ids > kTag41h12NCodes) return fail(ASL_EINVAL, "the code table holds %d ids (asked for %d)", kTag41h12NCodes, n_ids);
     if (d->pending) return fail(ASL_EINVAL, "a batch is in flight on this detector");
     d->fam.ncodes = n_ids <= 0 ? kTag41h12NCodes : n_ids;
+    return ASL_OK;
+}
+
+extern "C" int asl_detector_set_pnp_both_minima(asl_detector *d, int enabled)
+{
+    if (!d) return fail(ASL_EINVAL, "detector is NULL");
+    d->pnp_both_minima = enabled ? 1 : 0;
     return ASL_OK;
 }
 
@@ -438,9 +446,10 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     return ASL_OK;
 }
 
-static CamDev make_cam(const double *K, const double *dist, int n_dist, double tag_size)
+static CamDev make_cam(const asl_detector *d, const double *K, const double *dist, int n_dist, double tag_size)
 {
     CamDev c;
+    c.both_minima = d->pnp_both_minima; c.pad = 0;
     c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
     c.k1 = c.k2 = c.p1 = c.p2 = c.k3 = 0;
     if (dist && n_dist >= 4) { c.k1 = dist[0]; c.k2 = dist[1]; c.p1 = dist[2]; c.p2 = dist[3]; }
@@ -588,7 +597,7 @@ extern "C" int asl_submit_batch_device(asl_detector *d, const void *d_frames, in
     int rc = check_device_args(d, d_frames, n_frames, channels, w, h, stride, frame_pitch, n_dist, &g);
     if (rc) return rc;
     CamDev cam;
-    if (K) cam = make_cam(K, dist, n_dist, tag_size);
+    if (K) cam = make_cam(d, K, dist, n_dist, tag_size);
     return submit_batch(d, (const uint8_t *)d_frames, g, (hipStream_t)stream, K ? &cam : nullptr);
 }
 
@@ -646,7 +655,7 @@ extern "C" int asl_detect_batch_pose_u8(asl_detector *d, const uint8_t *const *f
         if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
         HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
     }
-    CamDev cam = make_cam(K, dist, n_dist, tag_size);
+    CamDev cam = make_cam(d, K, dist, n_dist, tag_size);
     int rcs = submit_batch(d, d->in.p, g, nullptr, &cam);
     if (rcs) return rcs;
     return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
@@ -730,7 +739,7 @@ extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const 
     HIPCHK(hipSetDevice(d->device));
     if (d->pnp_corners.ensure((size_t)N * 8) || d->pnp_out.ensure((size_t)N * 22) || d->pnp_ok.ensure((size_t)N))
         return fail(ASL_ENOMEM, "PnP workspace allocation failed");
-    CamDev cam = make_cam(K, dist, n_dist, tag_size);
+    CamDev cam = make_cam(d, K, dist, n_dist, tag_size);
     HIPCHK(hipMemcpy(d->pnp_corners.p, corners, sizeof(float) * 8 * (size_t)N, hipMemcpyHostToDevice));
     double *dr = d->pnp_out.p, *dt = dr + 3 * (size_t)N, *dT = dt + 3 * (size_t)N;
     hipLaunchKernelGGL(k_pnp_batch, dim3((N + pnp_lpw((size_t)N) - 1) / pnp_lpw((size_t)N)), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p, pnp_lpw((size_t)N));

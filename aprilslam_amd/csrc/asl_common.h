@@ -86,6 +86,8 @@ struct FamilyDev {
 struct CamDev {
     double fx, fy, cx, cy, k1, k2, p1, p2, k3;
     double half;  // tag_size/2 rounded through float32 as the reference does
+    int both_minima;  // 0 (default): the minimum the homography start leads to, like cv2.solvePnP(ITERATIVE); 1: the better of the two planar poses
+    int pad;
 };
 
 // counters living in device memory (zeroed per batch)

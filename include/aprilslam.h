@@ -74,6 +74,11 @@ void asl_detector_destroy(asl_detector *det);
    detector therefore decodes ids 0..4 only.  n_ids <= 0 opens the whole table (synthetic scenes rendered from
    the same table), n_ids > 0 keeps ids 0..n_ids-1. */
 int asl_detector_set_id_limit(asl_detector *det, int n_ids);
+/* A planar tag has two poses that reproject almost equally well.  cv2.solvePnP(ITERATIVE), which the reference calls
+   (tag_detector.py:41), returns the one its homography start leads to, and so does this library by default (enabled = 0).
+   enabled = 1 refines the mirrored pose as well and keeps the one with the lower reprojection error (IPPE's
+   two-solution test): better orientation for small, near-frontal tags, but no longer what the reference computes. */
+int asl_detector_set_pnp_both_minima(asl_detector *det, int enabled);
 const char *asl_last_error(void);
 /* "aprilslam <version> gfx950 ..." */
 const char *asl_version(void);
