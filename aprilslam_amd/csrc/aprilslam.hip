@@ -75,7 +75,7 @@ struct asl_detector {
     DevBuf<int> slot_cluster;
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
-    DevBuf<double> scratch, quadH;
+    DevBuf<double> scratch, quadH, wtab;
     DevBuf<DetRec> dets;
     // S8 on the device: per-frame index lists, counts and offsets, and the results in the ABI's layout
     DevBuf<unsigned int> frame_ndets, frame_idx, frame_nkeep, frame_off;
@@ -162,6 +162,18 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
         return fail(ASL_EDEVICE, "hipMemcpy(code book) failed");
     }
     d->fam.codes = d->d_codes;
+    if (d->wtab.ensure(WEIGHT_TABLE_N)) {
+        (void)hipFree(d->d_codes);
+        delete d;
+        return fail(ASL_ENOMEM, "hipMalloc(weight table) failed");
+    }
+    hipLaunchKernelGGL(k_weight_table, dim3((WEIGHT_TABLE_N + 255) / 256), dim3(256), 0, 0, d->wtab.p);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        d->wtab.release();
+        (void)hipFree(d->d_codes);
+        delete d;
+        return fail(ASL_EDEVICE, "weight table kernel failed");
+    }
     // class-3 quad fit uses 64 KB of dynamic LDS on top of a few hundred static bytes
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fit_quads<256, true, CLASS3_CAP / 256>), hipFuncAttributeMaxDynamicSharedMemorySize, QUAD_LDS_BYTES(CLASS3_CAP));
     *out = d;
@@ -180,7 +192,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->host_nkeep) (void)hipHostFree(d->host_nkeep);
     d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release(); d->tcut.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
-    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->dets.release();
+    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->wtab.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->aux_stream) (void)hipStreamDestroy(d->aux_stream);
@@ -352,7 +364,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     if (g.tw > 0 && g.th > 0)
         hipLaunchKernelGGL(k_tile_cut, dim3((g.tw + 63) / 64, (g.th + 3) / 4, B), dim3(64, 4), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
     STAGE("k_seg_tile");
-    hipLaunchKernelGGL(k_seg_tile, dim3(nwx, (g.sh + SEG_TH - 1) / SEG_TH, B), dim3(64), 0, st, d->dgray.p, d->tcut.p, g, nwx,
+    hipLaunchKernelGGL(k_seg_tile, dim3((nwx * ((g.sh + SEG_TH - 1) / SEG_TH) + SEG_TILE_WAVES - 1) / SEG_TILE_WAVES, 1, B), dim3(64 * SEG_TILE_WAVES), 0, st, d->dgray.p, d->tcut.p, g, nwx,
                        d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
     STAGE("k_seg_border_cols");
     if (nwx > 1) {
@@ -394,24 +406,24 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
     STAGE("k_fit_quads<0>");
     hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
-                       d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+                       d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
     STAGE("k_fit_quads<1>");
     // two wavefronts per cluster here: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
     hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), QUAD_LDS_BYTES(CLASS1_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
     STAGE("k_fit_quads<2>");
     hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS2_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
     STAGE("k_fit_quads<3>");
     hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS3_CAP), st, d->clusters.p,
                        d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
     STAGE("k_fit_quads<4>");
     hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
                        d->class_lists.p + (size_t)4 * d->max_clusters, d->counters.p, 4, d->max_clusters, 0, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p);
+                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
 
     STAGE("k_quad_compact");
     hipLaunchKernelGGL(k_quad_compact, dim3((d->max_clusters + 1023) / 1024), dim3(1024), 0, st, d->quads.p, d->counters.p, d->max_clusters,
@@ -679,6 +691,7 @@ extern "C" int asl_render_frames_device(asl_detector *d, void *d_frames, int n_f
 {
     if (!d || !d_frames || !d_planes || !d_textures) return fail(ASL_EINVAL, "NULL argument");
     if (n_frames <= 0 || w <= 0 || h <= 0 || max_planes <= 0 || tw <= 0 || th <= 0) return fail(ASL_EINVAL, "sizes must be positive");
+    if (max_planes > 64) return fail(ASL_EINVAL, "at most 64 planes per frame");
     if (stride < 3 * w || frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "stride / frame_pitch smaller than a BGR row / frame");
     if (dist && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 4 or 5");
     if (dist && !K) return fail(ASL_EINVAL, "lens coefficients need the camera matrix");
@@ -692,7 +705,7 @@ extern "C" int asl_render_frames_device(asl_detector *d, void *d_frames, int n_f
         cam.k1 = dist[0]; cam.k2 = dist[1]; cam.p1 = dist[2]; cam.p2 = dist[3]; cam.k3 = n_dist >= 5 ? dist[4] : 0.0;
         cam.distort = 1;
     }
-    hipLaunchKernelGGL(k_render, dim3((w + 63) / 64, (h + 3) / 4, (unsigned int)n_frames), dim3(64, 4), 0, (hipStream_t)stream, (uint8_t *)d_frames, w, h,
+    hipLaunchKernelGGL(k_render, dim3((w + RENDER_TW - 1) / RENDER_TW, (h + 4 * RENDER_TH - 1) / (4 * RENDER_TH), (unsigned int)n_frames), dim3(64, 4), 0, (hipStream_t)stream, (uint8_t *)d_frames, w, h,
                        stride, frame_pitch, (const RenderPlane *)d_planes, max_planes, (const uint8_t *)d_textures, tw, th, half, cam);
     HIPCHK(hipGetLastError());
     return ASL_OK;
@@ -824,10 +837,10 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
         if (bytes < sizeof(long long) * 16) return fail(ASL_EINVAL, "dst too small");
         long long *o = (long long *)dst;
         o[0] = g.nframes; o[1] = g.sw; o[2] = g.sh;
-        o[3] = d->last_counters[CNT_NCLUSTERS]; o[4] = d->last_counters[CNT_NPOINTS]; o[5] = 0;
+        o[3] = d->last_counters[CNT_NCLUSTERS]; o[4] = d->last_counters[CNT_NPOINTS]; o[5] = d->last_counters[CNT_NQUADS];
         o[6] = d->last_counters[CNT_NDETS]; o[7] = d->nslots; o[8] = d->max_clusters; o[9] = d->max_points; o[10] = d->max_dets;
         o[11] = d->last_counters[CNT_OVERFLOW_HASH]; o[12] = d->last_counters[CNT_OVERFLOW_CLUSTERS];
-        o[13] = d->last_counters[CNT_OVERFLOW_POINTS]; o[14] = d->last_counters[CNT_OVERFLOW_DETS]; o[15] = 0;
+        o[13] = d->last_counters[CNT_OVERFLOW_POINTS]; o[14] = d->last_counters[CNT_OVERFLOW_DETS]; o[15] = d->last_counters[CNT_CLASS0];
         *n_items = 16;
         return ASL_OK;
     }

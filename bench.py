@@ -74,7 +74,12 @@ def render_stream_device(det, n_frames, dev, phase=0.0, seed=20250620 + 1):
     det.render_frames_device(out.data_ptr(), n_frames, W, H, d_planes.data_ptr(), planes.shape[1], d_tex.data_ptr(), tex.shape[2], tex.shape[1],
                              0.5 * TAG_OUTER, stream=torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
-    return out, gts
+
+    def rerender(det2, stream):
+        """the same frames again, enqueued on `stream` (the `render_included` leg: frames produced on the device per step)"""
+        det2.render_frames_device(out.data_ptr(), n_frames, W, H, d_planes.data_ptr(), planes.shape[1], d_tex.data_ptr(), tex.shape[2], tex.shape[1],
+                                  0.5 * TAG_OUTER, stream=stream)
+    return out, gts, rerender
 
 
 def algorithmic_bytes(kernel, w, h, ch, f, runs=7200, points=18600):
@@ -302,7 +307,7 @@ def main():
     ndist = B if args.distinct <= 0 else min(args.distinct, B)
     # every rank = its own camera on the trajectory, one scene: the streams see the same tags from different places
     render_det = _lib.Detector("tagStandard41h12", device=local_rank, id_limit=0)
-    d_distinct, distinct_gt = render_stream_device(render_det, ndist, dev, phase=np.pi * rank / max(world, 1) / max(ndist, 1))
+    d_distinct, distinct_gt, rerender = render_stream_device(render_det, ndist, dev, phase=np.pi * rank / max(world, 1) / max(ndist, 1))
     render_det.close()
     d_frames = d_distinct if ndist == B else d_distinct.repeat((B + ndist - 1) // ndist, 1, 1, 1)[:B].contiguous()
     NCHK = min(32, ndist)  # frames checked against ground truth / handed to the CPU baseline
@@ -537,6 +542,21 @@ def main():
             line["pose_rmse_both_minima"] = pose_rmse_vs_ground_truth(alt[0], alt[1], alt[2], distinct_gt[:nchk])
             line["pose_rmse_both_minima"]["k_pnp_dets_ms"] = detectors[0].stage_times().get("k_pnp_dets")
             line["h2d_included"] = h2d_included(detectors[0], d_frames, K)
+            if ndist == B:
+                # the producer inside the step: every step first renders its B frames on the device, then detects
+                def rstep(k_):
+                    rerender(detectors[k_], streams[k_].cuda_stream)
+                    detectors[k_].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[k_].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
+                nrs = max(4, args.steps // 2)
+                torch.cuda.synchronize(dev)
+                tr0 = time.perf_counter()
+                for i_ in range(nrs):  # one workspace: the next render may not overwrite frames a running batch still reads
+                    rstep(0)
+                    detectors[0].collect()
+                torch.cuda.synchronize(dev)
+                tr = time.perf_counter() - tr0
+                line["render_included"] = {"value": B * nrs / tr, "unit": "frames/s", "steps": nrs, "ms_per_step": 1e3 * tr / nrs,
+                                           "note": "asl_render_frames_device (k_render) of the step's 1024 frames + the same batch, one workspace, synchronous; not the headline value"}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(distinct[:nchk], K)

@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
-"""Turn one round's raw measurement files (gpurun_out/) into the committed summaries under profiles/.
+"""Turn one round's raw measurement files (gpurun_out/, written by tools/profile_round.sh <tag> on the GPU box) into the
+committed summaries under profiles/.
 
-Inputs (produced on the GPU box, see DESIGN.md section 5 for the commands):
-  gpurun_out/bench_final.log            python bench.py                               (last line = the JSON)
-  gpurun_out/prof_f/f_kernel_stats.csv  rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline
-  gpurun_out/pmc_{fetch,write,sq1,sq2}.csv   tools/pmc_summary.py over rocprofv3 --pmc passes of
-                                        python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline
-usage: make_profiles.py <round tag, e.g. r01>"""
+Inputs:
+  gpurun_out/<tag>_bench_final.log        python bench.py                               (last line = the JSON)
+  gpurun_out/<tag>_f_kernel_stats.csv     rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline
+  gpurun_out/pmc_<tag>_{fetch,write,sq1,sq2}.csv   tools/pmc_summary.py over rocprofv3 --pmc passes of
+                                          python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline
+  gpurun_out/<tag>_config3.json, _config5.json, _gn_kernel_stats.csv, _pmc_gn.csv   tools/run_config3.py (plain, traced, counted)
+usage: make_profiles.py <round tag, e.g. r02>"""
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
-NAMES = {"void k_cluster_count<1024, false>": "k_cluster_count", "void k_cluster_count<4096, true>": "k_cluster_count<dense>",
-         "void k_decimate_minmax<3>": "k_decimate_minmax", "void k_decode<3>": "k_decode", "void k_refine<3>": "k_refine",
+# rocprofv3's kernel names -> the names bench.py reports (asl_stage_times)
+NAMES = {"void k_seg_points<4096, 2048, 4, 1>": "k_seg_points", "void k_seg_points<8192, 4352, 1, 2>": "k_seg_points<dense>",
+         "void k_decimate2_tiles<3>": "k_decimate_minmax", "void k_decimate_rest<3>": "k_decimate_rest",
+         "void k_decimate_minmax<3>": "k_decimate_minmax<generic>", "void k_decode<3>": "k_decode", "void k_refine<3>": "k_refine",
          "void k_fit_quads<64, true, 2>": "k_fit_quads<0>", "void k_fit_quads<128, true, 2>": "k_fit_quads<1>",
          "void k_fit_quads<256, true, 2>": "k_fit_quads<2>", "void k_fit_quads<256, true, 4>": "k_fit_quads<3>",
          "void k_fit_quads<256, false, 0>": "k_fit_quads<4>"}
+
+
+def short(k):
+    k = k.strip('"')
+    k = re.sub(r"\(.*$", "", k)          # drop the argument list
+    return NAMES.get(k, k)
 
 
 def table(path):
@@ -35,18 +46,18 @@ def ours(k):
     return not (k.startswith("__amd") or "at::native" in k)
 
 
-bench = json.loads(open(os.path.join(G, "bench_final.log")).read().strip().splitlines()[-1])
+bench = json.loads(open(os.path.join(G, tag + "_bench_final.log")).read().strip().splitlines()[-1])
 B = bench["config"]["batch_frames"]
 json.dump(bench, open(os.path.join(P, tag + "_bench_default.json"), "w"))
 
 dst = os.path.join(P, tag + "_f_kernel_stats.csv")
-shutil.copy(os.path.join(G, "prof_f", "f_kernel_stats.csv"), dst)
+shutil.copy(os.path.join(G, tag + "_f_kernel_stats.csv"), dst)
 body = open(dst).read()
-open(dst, "w").write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (B=%d, pipeline 2, 20 steps + 5 warm-up; 28 launches "
-                     "per kernel = 2 set-up + 5 warm-up + 20 timed + 1 isolated; only warm-up/timed launches overlap with the other workspace)\n" % B + body)
+open(dst, "w").write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (B=%d, pipeline 2, 20 steps + 5 warm-up; "
+                     "only warm-up/timed launches overlap with the other workspace)\n" % B + body)
 
-_, f = table(os.path.join(G, "pmc_fetch.csv"))
-_, w = table(os.path.join(G, "pmc_write.csv"))
+_, f = table(os.path.join(G, "pmc_%s_fetch.csv" % tag))
+_, w = table(os.path.join(G, "pmc_%s_write.csv" % tag))
 bpl = {}
 with open(os.path.join(P, tag + "_g_pmc_fetch_write_per_kernel.csv"), "w") as o:
     o.write("# rocprofv3 --pmc FETCH_SIZE (second run: --pmc WRITE_SIZE) -- python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline\n")
@@ -57,15 +68,15 @@ with open(os.path.join(P, tag + "_g_pmc_fetch_write_per_kernel.csv"), "w") as o:
         if not ours(k):
             continue
         fv, wv = f[k]["FETCH_SIZE"], w.get(k, {}).get("WRITE_SIZE", 0.0)
-        nm = NAMES.get(k, k)
+        nm = short(k)
         bpl[nm] = (fv + wv) * 1024.0
         o.write("%s,%d,%.1f,%.1f,%.0f\n" % (nm, int(f[k]["launches"]), fv, wv, (fv + wv) * 1024 / B))
 json.dump({"source": "profiles/%s_g_pmc_fetch_write_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, B=%d)" % (tag, B),
            "note": "raw FETCH_SIZE+WRITE_SIZE bytes per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950",
            "batch_frames": B, "bytes_per_launch": bpl}, open(os.path.join(P, tag + "_traffic.json"), "w"), indent=1)
 
-h1, a = table(os.path.join(G, "pmc_sq1.csv"))
-h2, b = table(os.path.join(G, "pmc_sq2.csv"))
+h1, a = table(os.path.join(G, "pmc_%s_sq1.csv" % tag))
+h2, b = table(os.path.join(G, "pmc_%s_sq2.csv" % tag))
 c1, c2 = h1[2:], h2[2:]
 iso = bench["kernel_ms_per_batch_isolated"]
 with open(os.path.join(P, tag + "_h_sq_counters_per_kernel.csv"), "w") as o:
@@ -77,9 +88,21 @@ with open(os.path.join(P, tag + "_h_sq_counters_per_kernel.csv"), "w") as o:
     for k in sorted(a):
         if not ours(k):
             continue
-        nm = NAMES.get(k, k)
+        nm = short(k)
         v = a[k]["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9) * 1e3
         t = iso.get(nm)
         o.write(nm + "," + ",".join("%.0f" % a[k][c] for c in c1) + "," + ",".join("%.0f" % b.get(k, {}).get(c, 0) for c in c2) +
                 ",%.3f,%s,%s\n" % (v, ("%.3f" % t) if t else "", ("%.2f" % (v / t)) if t else ""))
 print("value", bench["value"], "stage", bench["stage_threshold_segmentation"], "traffic/frame", sum(bpl.values()) / B)
+
+# the bench line was printed before this round's traffic file existed: fill the dominant kernel's traffic from the same passes
+dom = bench["roofline"]["kernel"]
+if bench["roofline"].get("traffic") is None and dom in bpl:
+    bench["roofline"]["traffic"] = bpl[dom]
+    bench["roofline"]["traffic_source"] = "profiles/%s_g_pmc_fetch_write_per_kernel.csv (same build, counted right after this run)" % tag
+    json.dump(bench, open(os.path.join(P, tag + "_bench_default.json"), "w"))
+
+for src, dst_name in ((tag + "_config3.json", tag + "_config3_detect_pnp_gn.json"), (tag + "_config5.json", tag + "_config5_single_gpu_detect_pnp_gn.json"),
+                      (tag + "_gn_kernel_stats.csv", tag + "_gn_kernel_stats.csv"), (tag + "_pmc_gn.csv", tag + "_gn_mfma_counters.csv")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst_name))

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything profiles/<tag>_* is made from, in one call on the GPU box:  bash tools/profile_round.sh r02
+# (then, back in the build container: python tools/make_profiles.py r02)
+set -e
+tag=$1
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd $R
+python bench.py > $O/${tag}_bench_final.log 2> $O/${tag}_bench_final.err
+echo "bench done: $(tail -c 300 $O/${tag}_bench_final.log | head -c 120)"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_f
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -- python3 $R/bench.py --no-cpu-baseline > $O/${tag}_prof_f.log 2>&1
+cp $(ls /tmp/prof_f/*/*kernel_stats.csv | head -1) $O/${tag}_f_kernel_stats.csv
+echo "kernel trace done"
+bash $R/tools/pmc_run.sh $tag
+# pose-graph back-end: configs[2] and the 4K / 200-tag shape, kernel trace and the MFMA counters of the 4K run
+cd $R
+python tools/run_config3.py > $O/${tag}_config3.json 2> /dev/null
+python tools/run_config3.py --width 3840 --height 2160 --tags 200 --frames 24 > $O/${tag}_config5.json 2> /dev/null
+cd /tmp
+rm -rf /tmp/prof_gn /tmp/pmc_gn
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gn -- python3 $R/tools/run_config3.py --width 3840 --height 2160 --tags 200 --frames 24 > /dev/null 2>&1
+cp $(ls /tmp/prof_gn/*/*kernel_stats.csv | head -1) $O/${tag}_gn_kernel_stats.csv
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d /tmp/pmc_gn -- python3 $R/tools/run_config3.py --width 3840 --height 2160 --tags 200 --frames 24 > $O/${tag}_pmc_gn.log 2>&1
+python3 $R/tools/pmc_summary.py /tmp/pmc_gn $O/${tag}_pmc_gn.csv
+echo "gn done"
