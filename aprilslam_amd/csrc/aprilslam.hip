@@ -72,7 +72,7 @@ struct asl_detector {
     DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, quad_list;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
-    DevBuf<int> slot_cluster;
+    DevBuf<unsigned long long> slot_cluster;  // per hash slot: offset | count << 32 of its cluster's segment
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
     DevBuf<double> scratch, quadH, wtab;
@@ -396,7 +396,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->clusters.p, d->slot_cluster.p, d->class_lists.p, d->max_clusters, d->max_points, d->counters.p);
     STAGE("k_point_place");
     hipLaunchKernelGGL(k_point_place, dim3(16, B), dim3(256), 0, st, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p, d->stage_cap,
-                       d->slot_cluster.p, d->clusters.p, d->points.p, d->counters.p);
+                       d->slot_cluster.p, d->points.p, d->counters.p);
 
     // one launch per size class; each walks its own cluster list (grid-stride)
     const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
