@@ -95,6 +95,20 @@ with open(os.path.join(P, tag + "_h_sq_counters_per_kernel.csv"), "w") as o:
                 ",%.3f,%s,%s\n" % (v, ("%.3f" % t) if t else "", ("%.2f" % (v / t)) if t else ""))
 print("value", bench["value"], "stage", bench["stage_threshold_segmentation"], "traffic/frame", sum(bpl.values()) / B)
 
+sq3 = os.path.join(G, "pmc_%s_sq3.csv" % tag)
+if os.path.exists(sq3):
+    h3, m3 = table(sq3)
+    with open(os.path.join(P, tag + "_i_valu_mix_per_kernel.csv"), "w") as o:
+        o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT -- python3 bench.py --steps 2 "
+                "--warmup 1 --pipeline 1 --no-cpu-baseline ; wave-instructions per launch (B=%d frames), shares of SQ_INSTS_VALU\n" % B)
+        o.write("kernel,SQ_INSTS_VALU,add_f64,mul_f64,fma_f64,trans_f64,int32,cvt\n")
+        for k in sorted(m3):
+            v = m3[k].get("SQ_INSTS_VALU", 0.0)
+            if not ours(k) or v <= 0:
+                continue
+            o.write("%s,%.0f,%s\n" % (short(k), v, ",".join("%.3f" % (m3[k].get(c, 0.0) / v) for c in (
+                "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT"))))
+
 # the bench line was printed before this round's traffic file existed: fill the dominant kernel's traffic from the same passes
 dom = bench["roofline"]["kernel"]
 if bench["roofline"].get("traffic") is None and dom in bpl:

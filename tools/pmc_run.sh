@@ -4,7 +4,7 @@
 # Counters are collected in their own runs (no trace domains), as the pool requires.
 set -e
 tag=$1
-want=${2:-"fetch write sq1 sq2"}
+want=${2:-"fetch write sq1 sq2 sq3"}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
