@@ -376,7 +376,21 @@ def main():
         t0 = time.perf_counter()
         res = None
         if args.rehearse:
-            block = adist.ObsBlock(adist.all_gather_observations(x["obs"].cpu().numpy().reshape(-1).view(adist.OBS_DTYPE).reshape(B, MT)))
+            # gloo gathers host memory: the block goes back to the device for the same graph kernels as the RCCL path
+            gathered = adist.all_gather_observations(x["obs"].cpu().numpy().reshape(-1).view(adist.OBS_DTYPE).reshape(B, MT))
+            block = adist.ObsBlock(gathered)
+            cid = slam.coordinate_id
+            if cid != -1:
+                d_block = torch.from_numpy(np.ascontiguousarray(gathered).view(np.uint8).reshape(world, B, MT, -1)).to(dev)
+                x["last"].zero_()
+                detectors[k].graph_frames_device(d_block.data_ptr(), world, B, MT, cid, x["pose"].data_ptr(), x["status"].data_ptr(),
+                                                 x["last"].data_ptr(), adist.MAX_IDS, picks_ptr=x["picks"].data_ptr(),
+                                                 stream=torch.cuda.current_stream(dev).cuda_stream)
+                x["h_pose"].copy_(x["pose"]); x["h_status"].copy_(x["status"]); x["h_last"].copy_(x["last"]); x["h_picks"].copy_(x["picks"])
+                nt = 1 + args.gn_frames
+                x["h_tail"][:, :nt * MT].copy_(d_block[:, B - nt:].reshape(world, nt * MT, -1))
+                torch.cuda.synchronize(dev)
+                res = (x["h_pose"].numpy(), x["h_status"].numpy(), x["h_last"].numpy().view(np.uint32))
         else:
             block = adist.ObsBlock(x["block"])
             if x["cid"] != -1 and x["cid"] == slam.coordinate_id:  # the kernel ran for the world tag the graph still has
@@ -488,14 +502,17 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg[dom],
                     "avg_launch_ms_isolated": isolated.get(dom), "algorithmic_bytes_per_frame": pts * 9}
-        # HBM traffic of the dominant kernel: not measurable live; taken from the committed rocprofv3 --pmc pass
+        # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc pass of the same build
+        tr = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if tr.get("batch_frames") == B and dom in tr["bytes_per_launch"]:
-                roof["traffic"] = tr["bytes_per_launch"][dom]
-                roof["traffic_source"] = tr["source"]
+            if tr.get("batch_frames") != B:
+                tr = None
         except Exception:
-            pass
+            tr = None
+        if tr and dom in tr["bytes_per_launch"]:
+            roof["traffic"] = tr["bytes_per_launch"][dom]
+            roof["traffic_source"] = tr["source"]
         line_rooflines = []
         for kname, ms_ in sorted(kernels_only.items(), key=lambda kv: -kv[1]):
             ab_ = algorithmic_bytes(kname, W, H, 3, 2)
@@ -508,6 +525,21 @@ def main():
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
         seg_gbs = seg_bytes * B / (seg * 1e-3) / 1e9 if seg > 0 else 0.0
+        # The headline roofline is the stage SURVEY 8(d) defines the algorithmic bytes for: threshold + segmentation is a
+        # chain of launches (K1-K9), each of them processes the same B frames, so "the kernel" is the chain and its launch
+        # duration the sum of its members' HIP-event durations inside the timed region (where the two pipeline parts share
+        # the GPU, so each member runs longer than alone; the isolated sum is given beside it).  The slowest single kernel
+        # with a byte model of its own is kept as `dominant_kernel`.
+        seg_live = sum(avg.get(k, 0.0) for k in seg_names)
+        live_gbs = seg_bytes * B / (seg_live * 1e-3) / 1e9 if seg_live > 0 else 0.0
+        stage_roof = {"kernel": "threshold + segmentation stage K1-K9 (k_decimate_minmax, k_tile_cut, k_seg_tile, k_seg_border_cols, k_seg_border_rows, "
+                                "k_seg_roots, k_hash_clear, k_seg_points, k_cluster_filter, k_point_place)",
+                      "bound": "hbm", "achieved": live_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": live_gbs / HBM_PEAK_GBS,
+                      "traffic": (sum(tr["bytes_per_launch"].get(k, 0.0) for k in seg_names) if tr else None),
+                      "traffic_source": tr["source"] if tr else None,
+                      "avg_launch_ms": seg_live, "avg_launch_ms_isolated": seg, "achieved_isolated": seg_gbs, "frac_isolated": seg_gbs / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_frame": seg_bytes, "units_per_launch": B,
+                      "members_ms": {k: avg.get(k, 0.0) for k in seg_names}, "dominant_kernel": roof}
         line = {
             "metric": "frames/sec at 1280x720, 20 tags/frame (detection + batched PnP)",
             "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -524,7 +556,7 @@ def main():
                 "frames_through_sequential_update": serial["seq_frames"], "lm_runs": serial["gn_runs"],
                 "lm_last": {k_: v_ for k_, v_ in (state.get("gn_last") or {}).items() if k_ != "camera_poses"} or None,
                 "graph_nodes": len(slam.graph.get_nodes()), "world_tag": slam.coordinate_id},
-            "roofline": roof,
+            "roofline": stage_roof,
             "stage_threshold_segmentation": {"ms_per_batch_isolated": seg, "algorithmic_read_bytes_per_frame": seg_bytes,
                                              "achieved_GBs": seg_gbs, "frac_of_hbm_peak": seg_gbs / HBM_PEAK_GBS},
             "kernel_rooflines_hbm": line_rooflines,

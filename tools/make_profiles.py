@@ -109,14 +109,20 @@ if os.path.exists(sq3):
             o.write("%s,%.0f,%s\n" % (short(k), v, ",".join("%.3f" % (m3[k].get(c, 0.0) / v) for c in (
                 "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT"))))
 
-# the bench line was printed before this round's traffic file existed: fill the dominant kernel's traffic from the same passes
-dom = bench["roofline"]["kernel"]
-if bench["roofline"].get("traffic") is None and dom in bpl:
-    bench["roofline"]["traffic"] = bpl[dom]
-    bench["roofline"]["traffic_source"] = "profiles/%s_g_pmc_fetch_write_per_kernel.csv (same build, counted right after this run)" % tag
+# the bench line was printed before this round's traffic file existed: fill the traffic fields from the same passes
+seg_members = list(bench["roofline"].get("members_ms", {}))
+if bench["roofline"].get("traffic") is None and seg_members:
+    src_note = "profiles/%s_g_pmc_fetch_write_per_kernel.csv (same build, counted right after this run)" % tag
+    bench["roofline"]["traffic"] = sum(bpl.get(k, 0.0) for k in seg_members)
+    bench["roofline"]["traffic_source"] = src_note
+    dk = bench["roofline"].get("dominant_kernel") or {}
+    if dk.get("traffic") is None and dk.get("kernel") in bpl:
+        dk["traffic"] = bpl[dk["kernel"]]
+        dk["traffic_source"] = src_note
     json.dump(bench, open(os.path.join(P, tag + "_bench_default.json"), "w"))
 
 for src, dst_name in ((tag + "_config3.json", tag + "_config3_detect_pnp_gn.json"), (tag + "_config5.json", tag + "_config5_single_gpu_detect_pnp_gn.json"),
-                      (tag + "_gn_kernel_stats.csv", tag + "_gn_kernel_stats.csv"), (tag + "_pmc_gn.csv", tag + "_gn_mfma_counters.csv")):
+                      (tag + "_gn_kernel_stats.csv", tag + "_gn_kernel_stats.csv"), (tag + "_pmc_gn.csv", tag + "_gn_mfma_counters.csv"),
+                      (tag + "_exchange_n1.json", tag + "_bench_exchange_n1.json"), (tag + "_rehearse_gpus2.json", tag + "_bench_rehearse_gpus2_gloo.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst_name))

@@ -25,3 +25,8 @@ cp $(ls /tmp/prof_gn/*/*kernel_stats.csv | head -1) $O/${tag}_gn_kernel_stats.cs
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d /tmp/pmc_gn -- python3 $R/tools/run_config3.py --width 3840 --height 2160 --tags 200 --frames 24 > $O/${tag}_pmc_gn.log 2>&1
 python3 $R/tools/pmc_summary.py /tmp/pmc_gn $O/${tag}_pmc_gn.csv
 echo "gn done"
+# the multi-GPU step: the exchange at N = 1 (RCCL, the collective degenerates to a copy) and a 2-rank gloo rehearsal on this one GPU
+cd $R
+python bench.py --exchange --no-cpu-baseline > $O/${tag}_exchange_n1.json 2> /dev/null
+python bench.py --gpus 2 --rehearse --steps 8 --warmup 3 --gn-every 4 --no-cpu-baseline > $O/${tag}_rehearse_gpus2.json 2> /dev/null
+echo "multi-gpu legs done"
