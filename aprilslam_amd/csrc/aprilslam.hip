@@ -691,7 +691,6 @@ extern "C" int asl_render_frames_device(asl_detector *d, void *d_frames, int n_f
 {
     if (!d || !d_frames || !d_planes || !d_textures) return fail(ASL_EINVAL, "NULL argument");
     if (n_frames <= 0 || w <= 0 || h <= 0 || max_planes <= 0 || tw <= 0 || th <= 0) return fail(ASL_EINVAL, "sizes must be positive");
-    if (max_planes > 64) return fail(ASL_EINVAL, "at most 64 planes per frame");
     if (stride < 3 * w || frame_pitch < (size_t)stride * (size_t)h) return fail(ASL_EINVAL, "stride / frame_pitch smaller than a BGR row / frame");
     if (dist && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 4 or 5");
     if (dist && !K) return fail(ASL_EINVAL, "lens coefficients need the camera matrix");

@@ -23,9 +23,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, NTAGS = 1280, 720, 20
+W, H, NTAGS = 1280, 720, 20  # --workload replaces them (main)
+# BASELINE.json configs the harness can run; "configs1" is the one the metric is quoted on (and the default)
+WORKLOADS = {
+    "configs1": {"w": 1280, "h": 720, "tags": 20, "batch": 1024, "partition": "streams", "exchange": False, "gn_every": 50,
+                 "name": "configs[1]: 1280x720 BGR stream, 20 tags/frame, detect + PnP"},
+    "configs2": {"w": 1920, "h": 1080, "tags": 50, "batch": 384, "partition": "streams", "exchange": True, "gn_every": 8,
+                 "name": "configs[2]: 1920x1080, 50 tags/frame, detect + PnP + pose-graph LM"},
+    "configs3": {"w": 1280, "h": 720, "tags": 20, "batch": 1024, "partition": "streams", "exchange": True, "gn_every": 50,
+                 "name": "configs[3]: one 1280x720 stream per GPU, all-gather of observations before the global solve"},
+    "configs4": {"w": 3840, "h": 2160, "tags": 200, "batch": 96, "partition": "frames", "exchange": True, "gn_every": 8,
+                 "name": "configs[4]: 3840x2160 dense 200-tag scene, frame i on GPU i mod N, graph update + pose-graph LM"},
+}
 TAG_OUTER, TAG_INNER = 18.0, 10.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MAXDET = 64  # detections per frame the result buffers hold (set from the workload)
 
 
 def make_frames(n_distinct, seed=20250620 + 1, with_gt=False, phase=0.0):
@@ -57,7 +69,7 @@ def camera_trajectory(n, phase=0.0):
     return cams
 
 
-def render_stream_device(det, n_frames, dev, phase=0.0, seed=20250620 + 1):
+def render_stream_device(det, n_frames, dev, phase=0.0, seed=20250620 + 1, take=None):
     """n_frames DISTINCT frames of the seeded 20-tag scene, rendered on the device (asl_render_frames_device: the
     reference renderer's image formation as a kernel, byte-identical to aprilslam_amd.synth.render_frame) straight into
     HBM.  Returns (uint8 tensor (n_frames, H, W, 3), per-frame ground truth {id: camera<-tag})."""
@@ -65,7 +77,8 @@ def render_stream_device(det, n_frames, dev, phase=0.0, seed=20250620 + 1):
     from aprilslam_amd import synth
     rng = np.random.default_rng(seed)
     tags = synth.random_scene(W, H, NTAGS, rng, tag_size_outer=TAG_OUTER)
-    cams = camera_trajectory(n_frames, phase)
+    # take = (rank, world): this rank's frames are every world-th pose of ONE stream (frame i on GPU i mod N)
+    cams = camera_trajectory(n_frames, phase) if take is None else camera_trajectory(n_frames * take[1])[take[0]::take[1]]
     planes, gts = synth.render_planes(W, H, tags, TAG_OUTER, cams)
     tex = synth.gray_textures([int(t["id"]) for t in tags])
     d_tex = torch.from_numpy(tex).to(dev)
@@ -265,16 +278,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1", help="BASELINE.json config to run (default: the one the metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (tiled to --batch); 0 = every frame of the batch is distinct")
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
-    ap.add_argument("--max-tags", type=int, default=NTAGS + 4, help="tag slots per frame in the exchanged observation records")
-    ap.add_argument("--gn-every", type=int, default=50, help="N > 1: pose-graph LM on a window every this many steps (0 = never)")
+    ap.add_argument("--max-tags", type=int, default=0, help="tag slots per frame in the exchanged observation records (0 = tags per frame + 4)")
+    ap.add_argument("--gn-every", type=int, default=-1, help="pose-graph LM on a window every this many steps of the exchange (0 = never, -1 = the workload's default)")
     ap.add_argument("--gn-frames", type=int, default=8, help="frames per stream in the LM window")
     ap.add_argument("--exchange", action="store_true", help="N = 1: run the exchange + graph update + LM of the multi-GPU step anyway (the collective degenerates to a copy)")
     args = ap.parse_args()
+    global W, H, NTAGS
+    wl = WORKLOADS[args.workload]
+    W, H, NTAGS = wl["w"], wl["h"], wl["tags"]
+    if args.batch <= 0:
+        args.batch = wl["batch"]
+    if args.max_tags <= 0:
+        args.max_tags = NTAGS + 4
+    if args.gn_every < 0:
+        args.gn_every = wl["gn_every"]
+    global MAXDET
+    MAXDET = max(64, 2 * NTAGS)
+    args.exchange = args.exchange or wl["exchange"]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -307,7 +333,10 @@ def main():
     ndist = B if args.distinct <= 0 else min(args.distinct, B)
     # every rank = its own camera on the trajectory, one scene: the streams see the same tags from different places
     render_det = _lib.Detector("tagStandard41h12", device=local_rank, id_limit=0)
-    d_distinct, distinct_gt, rerender = render_stream_device(render_det, ndist, dev, phase=np.pi * rank / max(world, 1) / max(ndist, 1))
+    if wl["partition"] == "frames":
+        d_distinct, distinct_gt, rerender = render_stream_device(render_det, ndist, dev, take=(rank, world))
+    else:
+        d_distinct, distinct_gt, rerender = render_stream_device(render_det, ndist, dev, phase=np.pi * rank / max(world, 1) / max(ndist, 1))
     render_det.close()
     d_frames = d_distinct if ndist == B else d_distinct.repeat((B + ndist - 1) // ndist, 1, 1, 1)[:B].contiguous()
     NCHK = min(32, ndist)  # frames checked against ground truth / handed to the CPU baseline
@@ -421,7 +450,7 @@ def main():
             serial["gn"].append(time.perf_counter() - t2)
 
     def finish(k):
-        dets, poses, npf = detectors[k].collect()
+        dets, poses, npf = detectors[k].collect(max_per_frame=MAXDET)
         if xchg:
             update_graph(k)
         for kk, v in detectors[k].stage_times().items():
@@ -448,7 +477,7 @@ def main():
     kernel_ms = {}
     for k in range(P):  # set-up, not a step: first use allocates each workspace (hipMalloc of several GB)
         detectors[k].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[k].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
-        detectors[k].collect()
+        detectors[k].collect(max_per_frame=MAXDET)
     for _ in range(args.warmup):
         step()
     res = drain()
@@ -477,7 +506,7 @@ def main():
 
     # one extra synchronous batch (nothing else on the GPU) for un-overlapped kernel durations
     detectors[0].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[0].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
-    last = detectors[0].collect()
+    last = detectors[0].collect(max_per_frame=MAXDET)
     last = (last[0].copy(), last[1].copy(), last[2].copy())
     isolated = detectors[0].stage_times()
 
@@ -485,9 +514,16 @@ def main():
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
         kernels_only = {k: v for k, v in avg.items() if k.startswith("k_")}
         # the slowest kernel of the step that has an HBM byte model (the per-cluster / per-quad kernels have none)
-        modelled = {k: v for k, v in kernels_only.items() if algorithmic_bytes(k, W, H, 3, 2) is not None}
+        if args.workload != "configs1":
+            # the per-run / per-point terms of the byte models: measured points of this scene, runs in the bench scene's proportion
+            pts_frame = float(detectors[0].debug_counters()[4]) / B
+            _ab = algorithmic_bytes
+            algorithmic_bytes_wl = lambda k_, w_, h_, c_, f_: _ab(k_, w_, h_, c_, f_, runs=int(0.39 * pts_frame), points=int(pts_frame))  # noqa: E731
+        else:
+            algorithmic_bytes_wl = algorithmic_bytes
+        modelled = {k: v for k, v in kernels_only.items() if algorithmic_bytes_wl(k, W, H, 3, 2) is not None}
         dom = max(modelled or kernels_only, key=(modelled or kernels_only).get)
-        ab = algorithmic_bytes(dom, W, H, 3, 2)
+        ab = algorithmic_bytes_wl(dom, W, H, 3, 2)
         roof = None
         if ab is not None:
             achieved = ab * B / (avg[dom] * 1e-3) / 1e9
@@ -515,7 +551,7 @@ def main():
             roof["traffic_source"] = tr["source"]
         line_rooflines = []
         for kname, ms_ in sorted(kernels_only.items(), key=lambda kv: -kv[1]):
-            ab_ = algorithmic_bytes(kname, W, H, 3, 2)
+            ab_ = algorithmic_bytes_wl(kname, W, H, 3, 2)
             if ab_ is not None:
                 gbs = ab_ * B / (ms_ * 1e-3) / 1e9
                 line_rooflines.append({"kernel": kname, "avg_launch_ms": ms_, "avg_launch_ms_isolated": isolated.get(kname),
@@ -541,13 +577,14 @@ def main():
                       "algorithmic_bytes_per_frame": seg_bytes, "units_per_launch": B,
                       "members_ms": {k: avg.get(k, 0.0) for k in seg_names}, "dominant_kernel": roof}
         line = {
-            "metric": "frames/sec at 1280x720, 20 tags/frame (detection + batched PnP)",
+            "metric": "frames/sec at %dx%d, %d tags/frame (detection + batched PnP%s)" % (W, H, NTAGS, ", graph update + pose-graph LM" if xchg else ""),
             "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/f64",
-            "data": "synthetic: %d distinct frames of a seeded 20-tag scene along a camera trajectory, rendered on the device into HBM (%d frames per step)" % (ndist, B),
-            "config": {"workload": "configs[1]: 1280x720 BGR stream, 20 tags/frame, detect + PnP", "batch_frames": B,
-                       "decimate": 2, "tags_found_per_batch": n_found, "pipeline_parts": P, "parallelism": "1 video stream per GPU"},
+            "data": "synthetic: %d distinct frames of a seeded %d-tag scene along a camera trajectory, rendered on the device into HBM (%d frames per step)" % (ndist, NTAGS, B),
+            "config": {"workload": wl["name"], "batch_frames": B,
+                       "decimate": 2, "tags_found_per_batch": n_found, "pipeline_parts": P,
+                       "parallelism": "frame i of one stream on GPU i mod N" if wl["partition"] == "frames" else "1 video stream per GPU"},
             "multi_gpu": None if not xchg else {
                 "exchange": "one all_gather_into_tensor per step of %d x %d asl_obs records (136 B) per rank = %.1f MB per rank, packed on the device" % (B, MT, B * MT * 136 / 1e6),
                 "backend": "gloo (rehearsal)" if args.rehearse else "nccl (RCCL)",
@@ -569,7 +606,7 @@ def main():
             # the same frames with the better of the two planar poses per tag (not what the reference computes: reported apart)
             detectors[0].set_pnp_both_minima(True)
             detectors[0].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[0].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
-            alt = detectors[0].collect()
+            alt = detectors[0].collect(max_per_frame=MAXDET)
             detectors[0].set_pnp_both_minima(False)
             line["pose_rmse_both_minima"] = pose_rmse_vs_ground_truth(alt[0], alt[1], alt[2], distinct_gt[:nchk])
             line["pose_rmse_both_minima"]["k_pnp_dets_ms"] = detectors[0].stage_times().get("k_pnp_dets")
@@ -584,7 +621,7 @@ def main():
                 tr0 = time.perf_counter()
                 for i_ in range(nrs):  # one workspace: the next render may not overwrite frames a running batch still reads
                     rstep(0)
-                    detectors[0].collect()
+                    detectors[0].collect(max_per_frame=MAXDET)
                 torch.cuda.synchronize(dev)
                 tr = time.perf_counter() - tr0
                 line["render_included"] = {"value": B * nrs / tr, "unit": "frames/s", "steps": nrs, "ms_per_step": 1e3 * tr / nrs,

@@ -183,7 +183,7 @@ typedef struct {
     int32_t pad;
 } asl_render_plane;   /* 96 bytes */
 
-/* Renders n_frames BGR frames of w x h pixels into device memory.  d_planes: n_frames x max_planes (<= 64) asl_render_plane
+/* Renders n_frames BGR frames of w x h pixels into device memory.  d_planes: n_frames x max_planes asl_render_plane
    (device), far to near, a record with tex < 0 ends a frame's list;
    d_textures: n_tex gray textures of tw x th bytes, rows top to bottom (device); half = half the side of the textured quad
    in scene units.  K (9 doubles) and dist (n_dist = 4 or 5) are host pointers and only needed for a camera with lens
