@@ -58,13 +58,14 @@ def pack_observations(dets, poses, n_per_frame, max_tags):
 def all_gather_observations(local_obs):
     """local_obs: (n_frames, max_tags) asl_obs records as a numpy structured array or as a torch uint8 tensor
     (n_frames, max_tags, 136) on the device.  Returns the same kind with a leading `world` axis, identical on every
-    rank: ONE all_gather_into_tensor.  Without an initialised process group the block is returned with world = 1."""
+    rank: ONE all_gather_into_tensor (also for a group of one rank: the same call path).  Without an initialised process
+    group the block is returned with world = 1."""
     import torch
     import torch.distributed as dist
 
     is_np = isinstance(local_obs, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(local_obs).view(np.uint8).reshape(local_obs.shape + (OBS_DTYPE.itemsize,))) if is_np else local_obs
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         out = t[None]
     else:
         world = dist.get_world_size()

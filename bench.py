@@ -315,7 +315,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.rehearse:
         local_rank = 0
-    if world > 1:
+    # a launcher-started single rank with the exchange on still goes through the process group (RCCL with one rank)
+    use_pg = world > 1 or (args.exchange and "RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -488,7 +490,7 @@ def main():
         if isinstance(v, list):
             v.clear()
     serial["seq_frames"] = 0; serial["gn_runs"] = 0
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -496,10 +498,10 @@ def main():
         step()
     drain()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -630,7 +632,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(distinct[:nchk], K)
         print(json.dumps(line))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
