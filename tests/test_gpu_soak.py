@@ -122,3 +122,48 @@ def test_device_observation_records_and_graph_frames(family):
         assert np.array_equal(a.graph.estimated_pose, b.graph.estimated_pose)
     finally:
         det.close()
+
+
+def test_full_size_batch_properties(family):
+    """BASELINE.json's batch (1024 frames of 1280x720 BGR, 20 tags per frame, resident in HBM) through properties that do
+    not depend on the size: every copy of a frame gives bit-identical results wherever it sits in the batch (frames do
+    not interact: no leak through the shared hash table, point pool, cluster lists or counters), a second run of the
+    same batch is bit-identical (atomics only decide WHERE things are stored, never what), and four of the frames
+    match the CPU oracle."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    det = _lib.Detector("tagStandard41h12", id_limit=0)
+    try:
+        ndist, B = 32, 1024
+        distinct, _gt, _ = bench.render_stream_device(det, ndist, dev)
+        perm = np.random.default_rng(7).permutation(B) % ndist  # which distinct frame sits at each batch position
+        frames = distinct[torch.from_numpy(perm).to(dev)].contiguous()
+        K = synth.camera_matrix(bench.W, bench.H)
+        runs = []
+        for _ in range(2):
+            d, p, n = det.detect_device(frames.data_ptr(), B, 3, bench.W, bench.H, K=K, dist=np.zeros(4), tag_size=bench.TAG_INNER, max_per_frame=64)
+            runs.append((d.copy(), p.copy(), n.copy()))
+        (d0, p0, n0), (d1, p1, n1) = runs
+        assert np.array_equal(n0, n1) and d0.tobytes() == d1.tobytes() and p0.tobytes() == p1.tobytes()
+        off = np.concatenate([[0], np.cumsum(n0)])
+        first = {}
+        for b in range(B):
+            sl = slice(off[b], off[b + 1])
+            cur = tuple(np.ascontiguousarray(d0[sl][f]).tobytes() for f in ("id", "hamming", "margin", "center", "corners")) + (p0[sl].tobytes(),)
+            k = int(perm[b])
+            if k in first:
+                assert cur == first[k], "frame %d (copy of distinct frame %d) differs from its first copy" % (b, k)
+            else:
+                first[k] = cur
+                assert n0[b] == bench.NTAGS
+        host = distinct[:4].cpu().numpy()
+        for k in range(4):
+            b = int(np.flatnonzero(perm == k)[0])
+            ref = O.detect_bgr(host[k], family)
+            mine = d0[off[b]:off[b + 1]]
+            assert [int(x["id"]) for x in mine] == [r["id"] for r in ref]
+            for x, r in zip(mine, ref):
+                assert np.abs(x["corners"] - r["corners"]).max() <= 1e-9
+    finally:
+        det.close()
