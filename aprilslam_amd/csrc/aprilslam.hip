@@ -340,10 +340,9 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     int thx = (g.sh + TILESZ - 1) / TILESZ;  // generic decimation kernel: tile rows
     unsigned int B = (unsigned int)g.nframes;
     d->nev = 0;
-    STAGE("memset");
-    HIPCHK(hipMemsetAsync(d->counters.p, 0, sizeof(long long) * CNT__N, st));
-    HIPCHK(hipMemsetAsync(d->frame_cursor.p, 0, sizeof(unsigned int) * B, st));
-    HIPCHK(hipMemsetAsync(d->frame_ndets.p, 0, sizeof(unsigned int) * B, st));
+    STAGE("k_hash_clear");
+    hipLaunchKernelGGL(k_hash_clear, dim3((std::max<unsigned int>(d->nslots, std::max<unsigned int>(B, CNT__N)) + 255) / 256), dim3(256), 0, st, d->hkeys.p,
+                       d->hcounts.p, d->nslots, d->counters.p, d->frame_cursor.p, d->frame_ndets.p, B);
 
     STAGE("k_decimate_minmax");
     if (g.f == 2) {
@@ -366,21 +365,19 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_seg_tile");
     hipLaunchKernelGGL(k_seg_tile, dim3((nwx * ((g.sh + SEG_TH - 1) / SEG_TH) + SEG_TILE_WAVES - 1) / SEG_TILE_WAVES, 1, B), dim3(64 * SEG_TILE_WAVES), 0, st, d->dgray.p, d->tcut.p, g, nwx,
                        d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
-    STAGE("k_seg_border_cols");
-    if (nwx > 1) {
-        const size_t nseams = (size_t)B * g.sh * (nwx - 1);
-        hipLaunchKernelGGL(k_seg_border_cols, dim3((unsigned int)((nseams + 63) / 64)), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
-                           d->counters.p);
+    STAGE("k_seg_border");
+    {
+        const size_t nseams = nwx > 1 ? (size_t)B * g.sh * (nwx - 1) : 0;
+        const unsigned int ncol_blocks = (unsigned int)((nseams + 63) / 64);
+        const int nrb = (g.sh - 1) / SEG_TH;
+        const unsigned int nrow_blocks = (unsigned int)nwx * (unsigned int)nrb * (unsigned int)B;
+        if (ncol_blocks + nrow_blocks > 0)
+            hipLaunchKernelGGL(k_seg_border, dim3(ncol_blocks + nrow_blocks), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p, d->counters.p,
+                               ncol_blocks, nrb > 0 ? nrb : 1);
     }
-    STAGE("k_seg_border_rows");
-    if ((g.sh - 1) / SEG_TH > 0)
-        hipLaunchKernelGGL(k_seg_border_rows, dim3(nwx, (g.sh - 1) / SEG_TH, B), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p,
-                           d->counters.p);
     STAGE("k_seg_roots");
     hipLaunchKernelGGL(k_seg_roots, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, nwx, d->parent.p, d->sizes.p);
 
-    STAGE("k_hash_clear");
-    hipLaunchKernelGGL(k_hash_clear, dim3((d->nslots + 255) / 256), dim3(256), 0, st, d->hkeys.p, d->hcounts.p, d->nslots);
     STAGE("k_seg_points");
     hipLaunchKernelGGL((k_seg_points<SEGP_PCAP, SEGP_RUNCAP, SEGP_NW, 1>), dim3(B, (nwx + SEGP_NW - 1) / SEGP_NW, pty), dim3(64 * SEGP_NW), 0, st,
                        d->wmask.p, d->bmask.p, g, nwx, d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p,

@@ -558,8 +558,8 @@ def main():
                 gbs = ab_ * B / (ms_ * 1e-3) / 1e9
                 line_rooflines.append({"kernel": kname, "avg_launch_ms": ms_, "avg_launch_ms_isolated": isolated.get(kname),
                                        "algorithmic_bytes_per_frame": ab_, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS})
-        seg_names = ("memset", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border_cols", "k_seg_border_rows", "k_seg_roots",
-                                             "k_hash_clear", "k_seg_points", "k_cluster_filter", "k_point_place")
+        seg_names = ("k_hash_clear", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border", "k_seg_roots", "k_seg_points", "k_cluster_filter",
+                     "k_point_place")
         seg = sum(isolated.get(k, 0.0) for k in seg_names)
         seg_bytes = stage_algorithmic_read_bytes(W, H, 3, 2)
         seg_gbs = seg_bytes * B / (seg * 1e-3) / 1e9 if seg > 0 else 0.0
@@ -570,8 +570,8 @@ def main():
         # with a byte model of its own is kept as `dominant_kernel`.
         seg_live = sum(avg.get(k, 0.0) for k in seg_names)
         live_gbs = seg_bytes * B / (seg_live * 1e-3) / 1e9 if seg_live > 0 else 0.0
-        stage_roof = {"kernel": "threshold + segmentation stage K1-K9 (k_decimate_minmax, k_tile_cut, k_seg_tile, k_seg_border_cols, k_seg_border_rows, "
-                                "k_seg_roots, k_hash_clear, k_seg_points, k_cluster_filter, k_point_place)",
+        stage_roof = {"kernel": "threshold + segmentation stage (k_hash_clear, k_decimate_minmax, k_tile_cut, k_seg_tile, k_seg_border, "
+                                "k_seg_roots, k_seg_points, k_cluster_filter, k_point_place)",
                       "bound": "hbm", "achieved": live_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": live_gbs / HBM_PEAK_GBS,
                       "traffic": (sum(tr["bytes_per_launch"].get(k, 0.0) for k in seg_names) if tr else None),
                       "traffic_source": tr["source"] if tr else None,
