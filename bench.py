@@ -32,7 +32,7 @@ WORKLOADS = {
                  "name": "configs[2]: 1920x1080, 50 tags/frame, detect + PnP + pose-graph LM"},
     "configs3": {"w": 1280, "h": 720, "tags": 20, "batch": 1024, "partition": "streams", "exchange": True, "gn_every": 50,
                  "name": "configs[3]: one 1280x720 stream per GPU, all-gather of observations before the global solve"},
-    "configs4": {"w": 3840, "h": 2160, "tags": 200, "batch": 96, "partition": "frames", "exchange": True, "gn_every": 8,
+    "configs4": {"w": 3840, "h": 2160, "tags": 200, "batch": 128, "partition": "frames", "exchange": True, "gn_every": 8,
                  "name": "configs[4]: 3840x2160 dense 200-tag scene, frame i on GPU i mod N, graph update + pose-graph LM"},
 }
 TAG_OUTER, TAG_INNER = 18.0, 10.0

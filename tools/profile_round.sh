@@ -32,5 +32,5 @@ python bench.py --gpus 2 --rehearse --steps 8 --warmup 3 --gn-every 4 --no-cpu-b
 # the other BASELINE.json configs through the same harness (graph update and pose-graph LM inside the timed region)
 python bench.py --workload configs2 --no-cpu-baseline > $O/${tag}_bench_configs2.json 2> /dev/null
 python bench.py --workload configs4 --no-cpu-baseline > $O/${tag}_bench_configs4_n1.json 2> /dev/null
-python bench.py --workload configs4 --gpus 2 --rehearse --steps 6 --warmup 2 --batch 48 --no-cpu-baseline > $O/${tag}_bench_configs4_rehearse_gpus2.json 2> /dev/null
+python bench.py --workload configs4 --gpus 2 --rehearse --steps 6 --warmup 2 --batch 64 --no-cpu-baseline > $O/${tag}_bench_configs4_rehearse_gpus2.json 2> /dev/null
 echo "multi-gpu legs done"
