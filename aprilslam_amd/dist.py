@@ -170,14 +170,16 @@ def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
     Returns (poses (world, n_frames, 4, 4), NaN where my_pose() is None; frames that took the sequential path)."""
     blk = obs if isinstance(obs, ObsBlock) else ObsBlock(obs)
     world, n_frames, max_tags = blk.shape
-    order = [(s, f) for f in range(n_frames) for s in range(world)]
+    def order():  # only the sequential paths walk the block frame by frame
+        return [(s, f) for f in range(n_frames) for s in range(world)]
     out = np.full((world, n_frames, 4, 4), np.nan)
     if slam.coordinate_id == -1:
         # nothing is self-contained before a world tag exists: the whole block goes through the mirror (once per run)
-        for (s, f), p in zip(order, _sequential(slam, blk.host(), order)):
+        od = order()
+        for (s, f), p in zip(od, _sequential(slam, blk.host(), od)):
             if p is not None:
                 out[s, f] = p
-        return out, len(order)
+        return out, len(od)
     if frames_result is None:
         frames_result = graph_frames_numpy(blk.host(), slam.coordinate_id)
     pose, status, last = frames_result
@@ -190,10 +192,11 @@ def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
         return out, 0
     # some frame needs the reference's sequential update: the state it reads depends on everything before it, so the
     # block goes through the mirror in order
-    for (s, f), p in zip(order, _sequential(slam, blk.host(), order)):
+    od = order()
+    for (s, f), p in zip(od, _sequential(slam, blk.host(), od)):
         if p is not None:
             out[s, f] = p
-    return out, len(order)
+    return out, len(od)
 
 
 def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None, tail=None):
