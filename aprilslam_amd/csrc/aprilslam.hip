@@ -401,11 +401,6 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     // per-cluster / per-quad costs balance out (workgroups without work leave at once)
     unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
     unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
-    STAGE("k_fit_quads<S>");
-    // nearly half of the clusters of a frame have at most 64 points: one point per lane, 4 KB of LDS
-    hipLaunchKernelGGL((k_fit_quads<64, true, CLASSS_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASSS_CAP), st, d->clusters.p,
-                       d->class_lists.p + (size_t)5 * d->max_clusters, d->counters.p, 5, d->max_clusters, CLASSS_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
     STAGE("k_fit_quads<0>");
     hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);

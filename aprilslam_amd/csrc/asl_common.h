@@ -12,10 +12,9 @@
 #define COS_CRITICAL_RAD 0.984807753012208 /* cos(10 deg) */
 #define HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define HASH_MAX_PROBE 512
-#define NCLASSES 6
+#define NCLASSES 5
 // size classes of the quad fit: points <= 128, <= 256, <= 512, <= 1024 (all-LDS), larger (global slab).  The LDS slab of a
 // workgroup is 64 bytes x cap, so every halving of the cap doubles the workgroups a CU can hold.
-#define CLASSS_CAP 64   /* class 5, the small clusters: one point per lane */
 #define CLASS0_CAP 128
 #define CLASS1_CAP 256
 #define CLASS2_CAP 512
@@ -106,7 +105,6 @@ enum {
     CNT_CLASS2,
     CNT_CLASS3,
     CNT_CLASS4,
-    CNT_CLASS5,  // clusters of at most CLASSS_CAP points
     CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
     CNT_UF_GUARD,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
     CNT_NKEEP,        // detections that survive the de-duplication (what the caller receives)

@@ -25,7 +25,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 NAMES = {"void k_seg_points<4096, 2048, 4, 1>": "k_seg_points", "void k_seg_points<8192, 4352, 1, 2>": "k_seg_points<dense>",
          "void k_decimate2_tiles<3>": "k_decimate_minmax", "void k_decimate_rest<3>": "k_decimate_rest",
          "void k_decimate_minmax<3>": "k_decimate_minmax<generic>", "void k_decode<3>": "k_decode", "void k_refine<3>": "k_refine",
-         "void k_fit_quads<64, true, 1>": "k_fit_quads<S>", "void k_fit_quads<64, true, 2>": "k_fit_quads<0>", "void k_fit_quads<128, true, 2>": "k_fit_quads<1>",
+         "void k_fit_quads<64, true, 2>": "k_fit_quads<0>", "void k_fit_quads<128, true, 2>": "k_fit_quads<1>",
          "void k_fit_quads<256, true, 2>": "k_fit_quads<2>", "void k_fit_quads<256, true, 4>": "k_fit_quads<3>",
          "void k_fit_quads<256, false, 0>": "k_fit_quads<4>"}
 
