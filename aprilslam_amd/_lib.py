@@ -41,7 +41,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_detector_set_pnp_both_minima", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_render_frames_device",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_graph_picks_device", "asl_render_frames_device",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -87,6 +87,7 @@ def load():
     L.asl_render_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, C.c_size_t, vp, i32, vp, i32, i32, C.c_double, dp, dp, i32, vp]
     L.asl_pack_observations_device.argtypes = [vp, vp, i32, vp]
     L.asl_graph_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]
+    L.asl_graph_picks_device.argtypes = [vp, vp, i32, i32, i32, vp, C.c_uint32, C.c_uint32, vp, i32, vp, vp]
     L.asl_debug_fetch.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.asl_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32, C.POINTER(i32)]
     L.asl_set_profiling.argtypes = [vp, i32]
@@ -263,6 +264,12 @@ class Detector:
                                               int(coordinate_id), C.c_void_p(int(pose_ptr)), C.c_void_p(int(status_ptr)),
                                               C.c_void_p(int(last_ptr)), int(n_ids), C.c_void_p(int(picks_ptr)) if picks_ptr else None,
                                               C.c_void_p(int(stream))))
+
+    def graph_picks_device(self, obs_ptr, world, n_frames, max_tags, status_ptr, order_lo, order_hi, last_ptr, n_ids, picks_ptr, stream=0):
+        """asl_graph_picks_device: last sightings + picks of the status-0 frames at positions [order_lo, order_hi)."""
+        check(self._L.asl_graph_picks_device(self._h, C.c_void_p(int(obs_ptr)), int(world), int(n_frames), int(max_tags), C.c_void_p(int(status_ptr)),
+                                             int(order_lo), int(order_hi), C.c_void_p(int(last_ptr)), int(n_ids), C.c_void_p(int(picks_ptr)),
+                                             C.c_void_p(int(stream))))
 
     def collect(self, max_per_frame=64):
         """Wait for the submitted batch; returns (dets, poses or None, n_per_frame).  The arrays are views into

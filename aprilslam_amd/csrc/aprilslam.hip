@@ -738,6 +738,23 @@ extern "C" int asl_graph_frames_device(asl_detector *d, const void *d_obs, int w
     return ASL_OK;
 }
 
+extern "C" int asl_graph_picks_device(asl_detector *d, const void *d_obs, int world, int n_frames, int max_tags, const uint8_t *d_status,
+                                      unsigned int order_lo, unsigned int order_hi, uint32_t *d_last, int n_ids, void *d_picks, void *stream)
+{
+    if (!d || !d_obs || !d_status || !d_last || !d_picks) return fail(ASL_EINVAL, "NULL argument");
+    if (world <= 0 || n_frames <= 0 || max_tags <= 0 || n_ids <= 0) return fail(ASL_EINVAL, "sizes must be positive");
+    if (order_lo > order_hi) return fail(ASL_EINVAL, "empty or reversed range");
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemsetAsync(d_last, 0, sizeof(uint32_t) * (size_t)n_ids, (hipStream_t)stream));
+    const unsigned int total = (unsigned int)world * (unsigned int)n_frames;
+    hipLaunchKernelGGL(k_graph_last_range, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
+                       d_status, order_lo, order_hi, (unsigned int *)d_last, n_ids);
+    hipLaunchKernelGGL(k_graph_pick, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
+                       (const unsigned int *)d_last, n_ids, (ObsRec *)d_picks);
+    HIPCHK(hipGetLastError());
+    return ASL_OK;
+}
+
 extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const double *K, const double *dist, int n_dist,
                                    double tag_size, double *rvec, double *tvec, double *T, uint8_t *ok, int N)
 {

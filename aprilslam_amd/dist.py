@@ -146,6 +146,33 @@ def graph_frames_numpy(obs, coordinate_id, n_ids=MAX_IDS):
     return pose, status, last
 
 
+def last_sightings_numpy(obs, status, lo, hi, n_ids=MAX_IDS):
+    """Host mirror of asl_graph_picks_device: (last (n_ids,) uint32, picks (2 * n_ids,) asl_obs) over the status-0 frames
+    at positions frame * world + stream in [lo, hi)."""
+    world, n_frames, max_tags = obs.shape
+    last = np.zeros(n_ids, dtype=np.uint32)
+    picks = np.zeros(2 * n_ids, dtype=OBS_DTYPE)
+    pos = np.arange(n_frames)[None, :] * world + np.arange(world)[:, None]
+    sel = (np.asarray(status).reshape(world, n_frames) == 0) & (pos >= lo) & (pos < hi)
+    s_idx, f_idx = np.nonzero(sel)
+    if len(s_idx):
+        rec = obs[s_idx, f_idx]
+        used = (rec["flags"] & 1) != 0
+        order = (f_idx * world + s_idx).astype(np.uint64) * max_tags
+        for j in range(max_tags):
+            u = used[:, j] & (rec["id"][:, j] >= 0) & (rec["id"][:, j] < n_ids)
+            np.maximum.at(last, rec["id"][u, j], (order[u] + j + 1).astype(np.uint32))
+        for t in np.nonzero(last)[0]:
+            key = int(last[t]) - 1
+            o, slot = key // max_tags, key % max_tags
+            picks[2 * t] = obs[o % world, o // world, slot]
+            picks[2 * t + 1] = obs[o % world, o // world, 0]
+    return last, picks
+
+
+MAX_SEQUENTIAL_FRAMES = 64  # more frames of a block than this needing the sequential update: the whole block takes it
+
+
 def _sequential(slam, obs, frames):
     """The reference's own update, frame by frame, for `frames` = iterable of (stream, frame) in order."""
     poses = []
@@ -161,12 +188,15 @@ def _sequential(slam, obs, frames):
     return poses
 
 
-def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
+def apply_block(slam, obs, frames_result=None, picks=None, tail=None, picker=None):
     """Apply one gathered block (numpy asl_obs records [world][n_frames][max_tags], or an ObsBlock) to `slam` in
     (frame, stream) order, deterministically and identically on every rank.  frames_result = (pose, status, last) of
     graph_frames (device kernel or numpy mirror) for this block and slam.coordinate_id; computed here with numpy if
     omitted.  picks (2 * n_ids asl_obs, from asl_graph_frames_device) and tail (the records of the last frame of every
     stream, (world, max_tags)) spare the bulk path every access to the block itself.
+    picker(lo, hi) -> (last, picks) over the status-0 frames at positions frame * world + stream in [lo, hi)
+    (asl_graph_picks_device; default: the numpy mirror on the host copy of the block) serves the case where a few frames
+    need the sequential update: the self-contained stretches between them are still applied in bulk.
     Returns (poses (world, n_frames, 4, 4), NaN where my_pose() is None; frames that took the sequential path)."""
     blk = obs if isinstance(obs, ObsBlock) else ObsBlock(obs)
     world, n_frames, max_tags = blk.shape
@@ -190,8 +220,50 @@ def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
         good = status == 0
         out[good] = pose[good]
         return out, 0
-    # some frame needs the reference's sequential update: the state it reads depends on everything before it, so the
-    # block goes through the mirror in order
+    # Some frames need the reference's sequential update (the world tag is not in view, or a PnP failed): what they read
+    # depends on everything before them.  If they are few, the self-contained stretches between them are applied in
+    # bulk (last sightings of the stretch) and only those frames go through the mirror, in order.
+    c0 = slam.coordinate_id
+    s_seq, f_seq = np.nonzero(status == 1)
+    pos_seq = np.sort(f_seq * world + s_seq)
+    if len(pos_seq) <= MAX_SEQUENTIAL_FRAMES:
+        if picker is None:
+            host = blk.host()
+            picker = lambda lo_, hi_: last_sightings_numpy(host, status, lo_, hi_)  # noqa: E731
+        pos_all = np.arange(n_frames)[None, :] * world + np.arange(world)[:, None]
+        lo, done, nseq = 0, True, 0
+        for p in list(pos_seq) + [world * n_frames]:
+            p = int(p)
+            if p > lo:
+                seg_status = np.where((pos_all >= lo) & (pos_all < p), status, 2).astype(np.uint8)
+                if (seg_status == 0).any():
+                    last_seg, picks_seg = picker(lo, p)
+                    _apply_steady(slam, blk, seg_status, np.asarray(last_seg), world, n_frames, max_tags, picks_seg, None, end_pos=p)
+                elif status[(p - 1) % world, (p - 1) // world] == 2:
+                    slam.visible_tags = []
+            if p < world * n_frames:
+                s, f = p % world, p // world
+                pose_p = _sequential(slam, blk.frames([(s, f)])[0][None, None], [(0, 0)])[0]
+                nseq += 1
+                if pose_p is not None:
+                    out[s, f] = pose_p
+                if slam.coordinate_id != c0:  # the world tag changed: the statuses computed for the old one no longer hold
+                    done = False
+                    lo = p + 1
+                    break
+            lo = p + 1
+        if done:
+            good = status == 0
+            out[good] = pose[good]
+            return out, nseq
+        # the rest of the block, in order, through the mirror
+        od = [(q % world, q // world) for q in range(lo, world * n_frames)]
+        good = (status == 0) & (pos_all < lo)
+        out[good] = pose[good]
+        for (s, f), pq in zip(od, _sequential(slam, blk.host(), od)):
+            if pq is not None:
+                out[s, f] = pq
+        return out, nseq + len(od)
     od = order()
     for (s, f), p in zip(od, _sequential(slam, blk.host(), od)):
         if p is not None:
@@ -199,7 +271,7 @@ def apply_block(slam, obs, frames_result=None, picks=None, tail=None):
     return out, len(od)
 
 
-def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None, tail=None):
+def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None, tail=None, end_pos=None):
     """State after a block of self-contained frames: every tag carries the values of the last frame that saw it, computed
     with the reference's operations (inv, @) on the host -- bit-identical to the sequential update."""
     c = slam.coordinate_id
@@ -234,3 +306,7 @@ def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None
         slam.visible_tags = rec["id"].tolist()
         graph.visible_tags = slam.visible_tags
         slam.my_pose()
+    # a stretch that ends with a frame without detections leaves nothing visible (slam.py:21-25)
+    end_pos = world * n_frames if end_pos is None else end_pos
+    if end_pos > 0 and status[(end_pos - 1) % world, (end_pos - 1) // world] == 2:
+        slam.visible_tags = []

@@ -413,6 +413,7 @@ def main():
             cid = slam.coordinate_id
             if cid != -1:
                 d_block = torch.from_numpy(np.ascontiguousarray(gathered).view(np.uint8).reshape(world, B, MT, -1)).to(dev)
+                x["d_block"] = d_block
                 x["last"].zero_()
                 detectors[k].graph_frames_device(d_block.data_ptr(), world, B, MT, cid, x["pose"].data_ptr(), x["status"].data_ptr(),
                                                  x["last"].data_ptr(), adist.MAX_IDS, picks_ptr=x["picks"].data_ptr(),
@@ -432,7 +433,16 @@ def main():
             picks = x["h_picks"].numpy().reshape(-1).view(adist.OBS_DTYPE)
             tail_frames = x["h_tail"].numpy()[:, :nt * MT].reshape(-1).view(adist.OBS_DTYPE).reshape(world, nt, MT)
         t1 = time.perf_counter()
-        poses, nseq = adist.apply_block(slam, block, res, picks=picks, tail=None if tail_frames is None else tail_frames[:, -1])
+        def picker(lo, hi):
+            """last sightings of a stretch of the block on the device (a few frames needed the sequential update)"""
+            src = x["block"] if not args.rehearse else x["d_block"]
+            detectors[k].graph_picks_device(src.data_ptr(), world, B, MT, x["status"].data_ptr(), lo, hi, x["last"].data_ptr(), adist.MAX_IDS,
+                                            x["picks"].data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+            x["h_last"].copy_(x["last"]); x["h_picks"].copy_(x["picks"])
+            torch.cuda.synchronize(dev)
+            return x["h_last"].numpy().view(np.uint32).copy(), x["h_picks"].numpy().reshape(-1).view(adist.OBS_DTYPE).copy()
+        poses, nseq = adist.apply_block(slam, block, res, picks=picks, tail=None if tail_frames is None else tail_frames[:, -1],
+                                        picker=picker if res is not None else None)
         t2 = time.perf_counter()
         serial["gather"].append(t1 - t0); serial["graph"].append(t2 - t1); serial["seq_frames"] += nseq
         state["blocks"] = state.get("blocks", 0) + 1

@@ -172,6 +172,13 @@ int asl_pack_observations_device(asl_detector *det, void *d_obs, int max_tags, v
 int asl_graph_frames_device(asl_detector *det, const void *d_obs, int world, int n_frames, int max_tags, int coordinate_id,
                             double *d_pose, uint8_t *d_status, uint32_t *d_last, int n_ids, void *d_picks, void *stream);
 
+/* Last sightings and picks as above, restricted to the status-0 frames whose position frame*world + stream lies in
+   [order_lo, order_hi) (d_status from asl_graph_frames_device; d_last is zeroed here).  The host applies the
+   self-contained stretches of a block between two frames that need the sequential update with it
+   (aprilslam_amd/dist.py: apply_block). */
+int asl_graph_picks_device(asl_detector *det, const void *d_obs, int world, int n_frames, int max_tags, const uint8_t *d_status,
+                           unsigned int order_lo, unsigned int order_hi, uint32_t *d_last, int n_ids, void *d_picks, void *stream);
+
 /* ---- before the detector: the image-formation step on the device (reference src/simulation/renderer.py:197-274:
    purple clear colour, one GL_LINEAR-textured quad per tag, BGR read-back).  One plane per visible tag and frame, in
    painter's order (far to near); a plane with tex < 0 ends a frame's list. */

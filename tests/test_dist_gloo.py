@@ -154,3 +154,51 @@ def test_shard_frames():
     shards = [adist.shard_frames(10, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(10))
     assert shards[1] == [1, 5, 9]
+
+
+def test_segmented_update_randomised():
+    """Blocks with several frames that need the sequential update (world tag out of view, failed PnP), empty frames also at
+    the end of a stretch, and world-tag switches in the middle of a block: the segmented bulk path (last sightings of every
+    self-contained stretch + the mirror for the frames in between) ends in exactly the state of the sequential update."""
+    import contextlib
+    import io
+    from aprilslam_amd import dist as adist, synth
+    rng = np.random.default_rng(7)
+    a, b = _new_slam(), _new_slam()
+    world, n_frames, max_tags = 3, 12, 7
+    bulk_frames = 0
+    for blk_i in range(40):
+        obs = np.zeros((world, n_frames, max_tags), dtype=adist.OBS_DTYPE)
+        obs["id"] = -1
+        low = 3 if blk_i < 6 else (1 if blk_i < 14 else 0)  # lower ids appear later: the world tag switches twice
+        for s in range(world):
+            for f in range(n_frames):
+                u = rng.random()
+                pool = np.arange(low, 9)
+                ids = sorted(rng.choice(pool, size=rng.integers(1, min(max_tags, len(pool)) + 1), replace=False).tolist())
+                if u < 0.10:
+                    ids = []
+                elif u < 0.85 and a.coordinate_id >= 0 and a.coordinate_id not in ids and len(ids) < max_tags and a.coordinate_id >= low:
+                    ids = sorted(ids + [a.coordinate_id])[:max_tags]
+                    if a.coordinate_id not in ids:
+                        ids = sorted([a.coordinate_id] + ids[:-1])
+                for j, i in enumerate(ids):
+                    T = synth.camera_from_tag([rng.uniform(-20, 20), rng.uniform(-10, 10), -rng.uniform(40, 90)], rng.uniform(-20, 20, 3))
+                    obs["id"][s, f, j] = i
+                    obs["flags"][s, f, j] = 1 if rng.random() < 0.02 else 3
+                    obs["T"][s, f, j] = T[:3].ravel()
+        pa, nseq = adist.apply_block(a, obs)
+        bulk_frames += world * n_frames - nseq
+        order = [(s, f) for f in range(n_frames) for s in range(world)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            pb = adist._sequential(b, obs, order)
+        for (s, f), p in zip(order, pb):
+            assert np.isnan(pa[s, f]).all() if p is None else np.abs(pa[s, f] - p).max() < 1e-12, (blk_i, s, f)
+        ga, gb = a.graph.get_nodes(), b.graph.get_nodes()
+        assert sorted(ga) == sorted(gb) and a.coordinate_id == b.coordinate_id, blk_i
+        for k in ga:
+            assert np.array_equal(ga[k].local, gb[k].local) and np.array_equal(ga[k].world, gb[k].world), (blk_i, k)
+            assert (ga[k].reference, ga[k].weight, ga[k].updated, ga[k].visible) == (gb[k].reference, gb[k].weight, gb[k].updated, gb[k].visible), (blk_i, k)
+        assert np.array_equal(a.graph.estimated_pose, b.graph.estimated_pose) and a.visible_tags == b.visible_tags, blk_i
+    assert bulk_frames > 0.5 * 40 * world * n_frames  # most frames did take the bulk path
+    assert a.coordinate_id == 0

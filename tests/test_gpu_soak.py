@@ -167,3 +167,49 @@ def test_full_size_batch_properties(family):
                 assert np.abs(x["corners"] - r["corners"]).max() <= 1e-9
     finally:
         det.close()
+
+
+def test_device_last_sightings_of_a_stretch(family):
+    """asl_graph_picks_device against its numpy mirror: last sightings and picks over ranges of a gathered block that holds
+    frames without the world tag and empty frames."""
+    import torch
+    from aprilslam_amd import dist as adist
+    rng = np.random.default_rng(11)
+    world, n_frames, max_tags = 3, 40, 6
+    obs = np.zeros((world, n_frames, max_tags), dtype=adist.OBS_DTYPE)
+    obs["id"] = -1
+    for s in range(world):
+        for f in range(n_frames):
+            u = rng.random()
+            ids = [] if u < 0.1 else sorted(rng.choice(np.arange(1, 9), size=rng.integers(1, max_tags - 1), replace=False).tolist())
+            if ids and u > 0.25:
+                ids = [0] + ids
+            for j, i in enumerate(ids):
+                obs["id"][s, f, j] = i
+                obs["flags"][s, f, j] = 3
+                obs["T"][s, f, j] = synth.camera_from_tag([rng.uniform(-20, 20), rng.uniform(-10, 10), -rng.uniform(40, 90)], rng.uniform(-20, 20, 3))[:3].ravel()
+    dev = torch.device("cuda", 0)
+    d_obs = torch.from_numpy(obs.view(np.uint8).reshape(world, n_frames, max_tags, -1)).to(dev)
+    pose = torch.zeros((world * n_frames, 16), dtype=torch.float64, device=dev)
+    status = torch.zeros(world * n_frames, dtype=torch.uint8, device=dev)
+    last = torch.zeros(adist.MAX_IDS, dtype=torch.int32, device=dev)
+    picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    det = _lib.Detector("tagStandard41h12")
+    try:
+        det.graph_frames_device(d_obs.data_ptr(), world, n_frames, max_tags, 0, pose.data_ptr(), status.data_ptr(), last.data_ptr(), adist.MAX_IDS)
+        torch.cuda.synchronize()
+        st = status.cpu().numpy().reshape(world, n_frames)
+        _, st_ref, _ = adist.graph_frames_numpy(obs, 0, adist.MAX_IDS)
+        assert np.array_equal(st, st_ref) and (st == 1).sum() > 3 and (st == 2).sum() > 3
+        for lo, hi in [(0, world * n_frames), (0, 17), (17, 58), (58, 59), (100, 120)]:
+            det.graph_picks_device(d_obs.data_ptr(), world, n_frames, max_tags, status.data_ptr(), lo, hi, last.data_ptr(), adist.MAX_IDS, picks.data_ptr())
+            torch.cuda.synchronize()
+            l_ref, p_ref = adist.last_sightings_numpy(obs, st, lo, hi)
+            l_dev = last.cpu().numpy().view(np.uint32)
+            assert np.array_equal(l_dev, l_ref), (lo, hi)
+            p_dev = picks.cpu().numpy().reshape(-1).view(adist.OBS_DTYPE)
+            seen = np.nonzero(l_ref)[0]
+            for t in seen:
+                assert p_dev[2 * t].tobytes() == p_ref[2 * t].tobytes() and p_dev[2 * t + 1].tobytes() == p_ref[2 * t + 1].tobytes()
+    finally:
+        det.close()
