@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""One-off randomised parity sweep, GPU against the CPU restatement (test infrastructure: uses oracle/ like tests/ do):
+random frame sizes (also odd ones and sizes around the 64-pixel word / 32-row tile boundaries), tag counts, noise levels,
+camera poses, decimations and ragged batches.  Prints the first mismatch or a summary.  usage: fuzz_parity.py [n_batches] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from aprilslam_amd import _lib, synth  # noqa: E402
+from aprilslam_amd.families import get_family  # noqa: E402
+
+
+def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    fam = get_family()
+    dets = {d: _lib.Detector("tagStandard41h12", decimate=float(d), id_limit=0) for d in (1, 2, 3)}
+    edge = [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 640, 641, 1279, 1280, 1281]
+    nframes = ntags_found = 0
+    t0 = time.time()
+    for b in range(nb):
+        dec = int(rng.choice([1, 2, 2, 2, 3]))
+        w = int(rng.choice(edge)) * dec if rng.random() < 0.4 else int(rng.integers(96, 1400))
+        h = int(rng.choice(edge[:12])) * dec if rng.random() < 0.4 else int(rng.integers(96, 900))
+        w, h = min(w, 1600), min(h, 1000)
+        n = int(rng.integers(1, 4))
+        frames = []
+        for _ in range(n):
+            tags = synth.random_scene(w, h, int(rng.integers(1, 10)), rng)
+            pos, rot = tuple(rng.uniform(-3, 3, 3)), tuple(rng.uniform(-4, 4, 3))
+            f, _ = synth.render_frame(w, h, tags, 18.0, cam_position=pos, cam_rotation_deg=rot, noise_sigma=float(rng.choice([0, 0, 1, 3])), rng=rng)
+            frames.append(f)
+        frames = np.stack(frames)
+        K = synth.camera_matrix(w, h)
+        d, p, npf = dets[dec].detect_host(frames, K=K, dist=np.zeros(4), tag_size=10.0)
+        start = 0
+        for k in range(n):
+            ref = O.detect_gray(O.bgr2gray(frames[k]), fam, dec)
+            mine = d[start:start + npf[k]]
+            start += npf[k]
+            ok = [int(x["id"]) for x in mine] == [r["id"] for r in ref]
+            ok = ok and all(int(x["hamming"]) == r["hamming"] and np.abs(x["corners"] - r["corners"]).max() <= 1e-9 and
+                            np.float32(x["margin"]) == np.float32(r["margin"]) for x, r in zip(mine, ref))
+            if not ok:
+                print("MISMATCH batch %d frame %d: %dx%d decimate %d seed %d" % (b, k, w, h, dec, seed))
+                print(" gpu", [(int(x["id"]), int(x["hamming"])) for x in mine])
+                print(" cpu", [(r["id"], r["hamming"]) for r in ref])
+                sys.exit(1)
+            ntags_found += len(ref)
+        nframes += n
+        if b % 25 == 24:
+            print("batch %d: %d frames, %d tags, %.0f s" % (b + 1, nframes, ntags_found, time.time() - t0), flush=True)
+    print("OK: %d batches, %d frames, %d tags identical (ids, hamming, margin exactly; corners <= 1e-9 px), %.0f s" % (nb, nframes, ntags_found, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
