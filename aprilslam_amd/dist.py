@@ -200,75 +200,77 @@ def apply_block(slam, obs, frames_result=None, picks=None, tail=None, picker=Non
     Returns (poses (world, n_frames, 4, 4), NaN where my_pose() is None; frames that took the sequential path)."""
     blk = obs if isinstance(obs, ObsBlock) else ObsBlock(obs)
     world, n_frames, max_tags = blk.shape
-    def order():  # only the sequential paths walk the block frame by frame
-        return [(s, f) for f in range(n_frames) for s in range(world)]
+    total = world * n_frames
     out = np.full((world, n_frames, 4, 4), np.nan)
-    if slam.coordinate_id == -1:
-        # nothing is self-contained before a world tag exists: the whole block goes through the mirror (once per run)
-        od = order()
-        for (s, f), p in zip(od, _sequential(slam, blk.host(), od)):
-            if p is not None:
-                out[s, f] = p
-        return out, len(od)
-    if frames_result is None:
-        frames_result = graph_frames_numpy(blk.host(), slam.coordinate_id)
-    pose, status, last = frames_result
-    pose = np.asarray(pose).reshape(world, n_frames, 4, 4)
-    status = np.asarray(status).reshape(world, n_frames)
-    if not (status == 1).any():
-        _apply_steady(slam, blk, status, np.asarray(last), world, n_frames, max_tags, picks, tail)
-        good = status == 0
-        out[good] = pose[good]
-        return out, 0
-    # Some frames need the reference's sequential update (the world tag is not in view, or a PnP failed): what they read
-    # depends on everything before them.  If they are few, the self-contained stretches between them are applied in
-    # bulk (last sightings of the stretch) and only those frames go through the mirror, in order.
-    c0 = slam.coordinate_id
-    s_seq, f_seq = np.nonzero(status == 1)
-    pos_seq = np.sort(f_seq * world + s_seq)
-    if len(pos_seq) <= MAX_SEQUENTIAL_FRAMES:
-        if picker is None:
+    pos_all = np.arange(n_frames)[None, :] * world + np.arange(world)[:, None]
+    lo, nseq = 0, 0
+    given = frames_result is not None and slam.coordinate_id != -1
+
+    def one_frame(p):
+        s, f = p % world, p // world
+        pose_p = _sequential(slam, blk.frames([(s, f)])[0][None, None], [(0, 0)])[0]
+        if pose_p is not None:
+            out[s, f] = pose_p
+
+    while lo < total:
+        c0 = slam.coordinate_id
+        if c0 == -1:
+            # nothing is self-contained before a world tag exists: frame by frame until one does (once per run)
+            one_frame(lo)
+            lo, nseq = lo + 1, nseq + 1
+            continue
+        if given and lo == 0:
+            pose, status, last = frames_result
+            seg_picker, whole_picks = picker, picks
+        else:  # statuses for the world tag the graph has now (the block started without one, or it changed on the way)
+            pose, status, last = graph_frames_numpy(blk.host(), c0)
+            seg_picker, whole_picks = None, None
+        pose = np.asarray(pose).reshape(world, n_frames, 4, 4)
+        status = np.asarray(status).reshape(world, n_frames)
+        todo = pos_all >= lo
+        if lo == 0 and not (status == 1).any():
+            _apply_steady(slam, blk, status, np.asarray(last), world, n_frames, max_tags, whole_picks, tail if whole_picks is not None else None)
+            good = status == 0
+            out[good] = pose[good]
+            return out, nseq
+        # Some frames need the reference's sequential update (the world tag is not in view, or a PnP failed): what they
+        # read depends on everything before them.  If they are few, the self-contained stretches between them are applied
+        # in bulk (last sightings of the stretch) and only those frames go through the mirror, in order.
+        s_seq, f_seq = np.nonzero((status == 1) & todo)
+        pos_seq = np.sort(f_seq * world + s_seq)
+        if len(pos_seq) > MAX_SEQUENTIAL_FRAMES:
+            od = [(q % world, q // world) for q in range(lo, total)]
+            for (s, f), pq in zip(od, _sequential(slam, blk.host(), od)):
+                if pq is not None:
+                    out[s, f] = pq
+            return out, nseq + len(od)
+        if seg_picker is None:
             host = blk.host()
-            picker = lambda lo_, hi_: last_sightings_numpy(host, status, lo_, hi_)  # noqa: E731
-        pos_all = np.arange(n_frames)[None, :] * world + np.arange(world)[:, None]
-        lo, done, nseq = 0, True, 0
-        for p in list(pos_seq) + [world * n_frames]:
+            seg_picker = lambda lo_, hi_, st_=status: last_sightings_numpy(host, st_, lo_, hi_)  # noqa: E731
+        switched = False
+        start = lo
+        for p in list(pos_seq) + [total]:
             p = int(p)
             if p > lo:
                 seg_status = np.where((pos_all >= lo) & (pos_all < p), status, 2).astype(np.uint8)
                 if (seg_status == 0).any():
-                    last_seg, picks_seg = picker(lo, p)
+                    last_seg, picks_seg = seg_picker(lo, p)
                     _apply_steady(slam, blk, seg_status, np.asarray(last_seg), world, n_frames, max_tags, picks_seg, None, end_pos=p)
                 elif status[(p - 1) % world, (p - 1) // world] == 2:
                     slam.visible_tags = []
-            if p < world * n_frames:
-                s, f = p % world, p // world
-                pose_p = _sequential(slam, blk.frames([(s, f)])[0][None, None], [(0, 0)])[0]
+            lo = p
+            if p < total:
+                one_frame(p)
                 nseq += 1
-                if pose_p is not None:
-                    out[s, f] = pose_p
+                lo = p + 1
                 if slam.coordinate_id != c0:  # the world tag changed: the statuses computed for the old one no longer hold
-                    done = False
-                    lo = p + 1
+                    switched = True
                     break
-            lo = p + 1
-        if done:
-            good = status == 0
-            out[good] = pose[good]
-            return out, nseq
-        # the rest of the block, in order, through the mirror
-        od = [(q % world, q // world) for q in range(lo, world * n_frames)]
-        good = (status == 0) & (pos_all < lo)
+        good = (status == 0) & (pos_all >= start) & (pos_all < lo)
         out[good] = pose[good]
-        for (s, f), pq in zip(od, _sequential(slam, blk.host(), od)):
-            if pq is not None:
-                out[s, f] = pq
-        return out, nseq + len(od)
-    od = order()
-    for (s, f), p in zip(od, _sequential(slam, blk.host(), od)):
-        if p is not None:
-            out[s, f] = p
-    return out, len(od)
+        if not switched:
+            break
+    return out, nseq
 
 
 def _apply_steady(slam, blk, status, last, world, n_frames, max_tags, picks=None, tail=None, end_pos=None):
