@@ -53,11 +53,22 @@ def main():
                 print(" gpu", [(int(x["id"]), int(x["hamming"])) for x in mine])
                 print(" cpu", [(r["id"], r["hamming"]) for r in ref])
                 sys.exit(1)
+            if len(mine):  # PnP of the same corners (float32, as the reference passes them to solvePnP) on both sides
+                c32 = np.stack([np.asarray(x["corners"], dtype=np.float32) for x in mine])
+                orv, otv, _, ook = O.solve_pnp(c32, K, np.zeros(4), 10.0)
+                mp = p[start - npf[k]:start]
+                # both sides stop their LM when the step falls below 1e-10 of the pose scale: tvec agrees to 1e-6 units at the
+                # usual 100 units of distance, proportionally for the small far tags this sweep also produces
+                ttol = 1e-6 * np.maximum(1.0, np.linalg.norm(otv, axis=1) / 100.0)
+                if not (np.array_equal(mp["ok"].astype(bool), ook.astype(bool)) and np.abs(mp["rvec"] - orv).max() <= 1e-6 and
+                        (np.abs(mp["tvec"] - otv).max(axis=1) <= ttol).all()):
+                    print("PnP MISMATCH batch %d frame %d: %dx%d decimate %d seed %d" % (b, k, w, h, dec, seed))
+                    sys.exit(1)
             ntags_found += len(ref)
         nframes += n
         if b % 25 == 24:
             print("batch %d: %d frames, %d tags, %.0f s" % (b + 1, nframes, ntags_found, time.time() - t0), flush=True)
-    print("OK: %d batches, %d frames, %d tags identical (ids, hamming, margin exactly; corners <= 1e-9 px), %.0f s" % (nb, nframes, ntags_found, time.time() - t0))
+    print("OK: %d batches, %d frames, %d tags identical (ids, hamming, margin exactly; corners <= 1e-9 px; rvec <= 1e-6, tvec <= 1e-6 per 100 units of distance), %.0f s" % (nb, nframes, ntags_found, time.time() - t0))
 
 
 if __name__ == "__main__":
