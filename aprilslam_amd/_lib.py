@@ -41,7 +41,7 @@ assert QUAD_DTYPE.itemsize == C.sizeof(AslDebugQuad)
 
 EXPORTS = [
     "asl_detector_create", "asl_detector_destroy", "asl_detector_set_id_limit", "asl_detector_set_pnp_both_minima", "asl_last_error", "asl_version", "asl_detect_gray_u8",
-    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_graph_picks_device", "asl_render_frames_device",
+    "asl_detect_bgr_u8", "asl_detect_batch_u8", "asl_detect_batch_pose_u8", "asl_detect_batch_device", "asl_submit_batch_device", "asl_collect_batch", "asl_collect_batch_view", "asl_solve_pnp_batch", "asl_gn_solve", "asl_pack_observations_device", "asl_graph_frames_device", "asl_graph_picks_device", "asl_render_frames_device",
     "asl_debug_fetch", "asl_stage_times", "asl_set_profiling", "asl_debug_phase_cycles",
 ]
 
@@ -81,6 +81,7 @@ def load():
                                           vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.asl_submit_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.c_size_t, vp, dp, dp, i32, C.c_double]
     L.asl_collect_batch.argtypes = [vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.asl_collect_batch_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)]
     L.asl_solve_pnp_batch.argtypes = [vp, C.POINTER(C.c_float), dp, dp, i32, C.c_double, dp, dp, dp, u8p, i32]
     L.asl_gn_solve.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_double, i32,
                                dp, dp, i32, dp]
@@ -270,6 +271,23 @@ class Detector:
         check(self._L.asl_graph_picks_device(self._h, C.c_void_p(int(obs_ptr)), int(world), int(n_frames), int(max_tags), C.c_void_p(int(status_ptr)),
                                              int(order_lo), int(order_hi), C.c_void_p(int(last_ptr)), int(n_ids), C.c_void_p(int(picks_ptr)),
                                              C.c_void_p(int(stream))))
+
+    def collect_view(self):
+        """Wait for the submitted batch; (dets, poses or None, n_per_frame) as numpy VIEWS of the detector's page-locked result
+        buffers (asl_collect_batch_view: no copy) -- valid until the next submit on this detector."""
+        n_frames, want_poses = self._inflight
+        pd, pp, pn, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        check(self._L.asl_collect_batch_view(self._h, C.byref(pd), C.byref(pp), C.byref(pn), C.byref(n)))
+        nd = n.value
+
+        def view(ptr, dtype, count):
+            if not ptr or count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_char * (count * dtype.itemsize)).from_address(ptr), dtype=dtype, count=count)
+        dets = view(pd.value, DET_DTYPE, nd)
+        poses = view(pp.value, POSE_DTYPE, nd) if (want_poses and pp.value) else None
+        npf = view(pn.value, np.dtype(np.uint32), n_frames)
+        return dets, poses, npf
 
     def collect(self, max_per_frame=64):
         """Wait for the submitted batch; returns (dets, poses or None, n_per_frame).  The arrays are views into

@@ -618,6 +618,19 @@ extern "C" int asl_collect_batch(asl_detector *d, asl_detection *out, asl_pose *
     return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
 }
 
+extern "C" int asl_collect_batch_view(asl_detector *d, const asl_detection **out, const asl_pose **poses, const uint32_t **n_per_frame, int *n_out)
+{
+    if (!d || !out || !n_per_frame || !n_out) return fail(ASL_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(d->device));
+    const bool with_poses = d->p_has_cam;
+    int rc = collect_batch(d, nullptr, nullptr, 0, nullptr, n_out);  // waits, checks, fills the detector's page-locked result buffers
+    if (rc) return rc;
+    *out = reinterpret_cast<const asl_detection *>(d->host_det);
+    if (poses) *poses = with_poses ? reinterpret_cast<const asl_pose *>(d->host_pose) : nullptr;
+    *n_per_frame = d->host_nkeep;
+    return ASL_OK;
+}
+
 extern "C" int asl_detect_batch_device(asl_detector *d, const void *d_frames, int n_frames, int channels, int w, int h, int stride,
                                        size_t frame_pitch, void *stream, const double *K, const double *dist, int n_dist,
                                        double tag_size, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)

@@ -462,7 +462,7 @@ def main():
             serial["gn"].append(time.perf_counter() - t2)
 
     def finish(k):
-        dets, poses, npf = detectors[k].collect(max_per_frame=MAXDET)
+        dets, poses, npf = detectors[k].collect_view()  # views of the detector's page-locked result buffers: no host copy
         if xchg:
             update_graph(k)
         for kk, v in detectors[k].stage_times().items():

@@ -126,6 +126,11 @@ int asl_submit_batch_device(asl_detector *det, const void *d_frames, int n_frame
                             int n_dist, double tag_size);
 int asl_collect_batch(asl_detector *det, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame,
                       int *n_out);
+/* The same without the last copy: *out / *poses / *n_per_frame point into the detector's own page-locked result buffers
+   (*n_out detections in (frame, id) order, *poses = NULL for a batch submitted without a camera); they stay valid until
+   the next submit on this detector. */
+int asl_collect_batch_view(asl_detector *det, const asl_detection **out, const asl_pose **poses, const uint32_t **n_per_frame,
+                           int *n_out);
 
 /* Replaces cv2.solvePnP(ITERATIVE) + cv2.Rodrigues for N tags at once (reference
    tag_detector.py:30-52).  corners: N x 4 x 2 float32 (lb,rb,rt,lt), K row-major 3x3,

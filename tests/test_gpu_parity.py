@@ -303,7 +303,7 @@ def test_submit_collect_pipeline_equals_blocking_call(family):
             dets[k].submit_device(t.data_ptr(), 4, 3, 640, 360, stream=streams[k].cuda_stream, K=K, dist=np.zeros(4), tag_size=10.0)
             inflight.append(k)
         while inflight:
-            r = dets[inflight.pop(0)].collect()
+            r = dets[inflight.pop(0)].collect_view()  # the zero-copy form: views of the detector's own buffers
             got.append((r[0].copy(), r[1].copy(), r[2].copy()))
         for (d0, p0, n0), (d1, p1, n1) in zip(ref, got):
             assert np.array_equal(n0, n1) and np.array_equal(d0["id"], d1["id"]) and np.array_equal(d0["corners"], d1["corners"])
