@@ -29,6 +29,29 @@
 
 static thread_local std::string g_err;
 
+// Optional ROCTX ranges around the stage groups, for `rocprofv3 --marker-trace`: ASL_ROCTX=1 in the
+// environment loads the marker library at first use; without it these are two predictable branches.
+#include <dlfcn.h>
+static struct Markers {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    void load()
+    {
+        tried = true;
+        const char *e = getenv("ASL_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+} g_markers;
+static inline void range_push(const char *name) { if (!g_markers.tried) g_markers.load(); if (g_markers.push) g_markers.push(name); }
+static inline void range_pop() { if (g_markers.pop) g_markers.pop(); }
+
 static int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -340,6 +363,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     int thx = (g.sh + TILESZ - 1) / TILESZ;  // generic decimation kernel: tile rows
     unsigned int B = (unsigned int)g.nframes;
     d->nev = 0;
+    range_push("S0-S4 gray, decimate, threshold, segmentation, clusters");
     STAGE("k_hash_clear");
     hipLaunchKernelGGL(k_hash_clear, dim3((std::max<unsigned int>(d->nslots, std::max<unsigned int>(B, CNT__N)) + 255) / 256), dim3(256), 0, st, d->hkeys.p,
                        d->hcounts.p, d->nslots, d->counters.p, d->frame_cursor.p, d->frame_ndets.p, B);
@@ -401,6 +425,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     // per-cluster / per-quad costs balance out (workgroups without work leave at once)
     unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
     unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
+    range_pop();
+    range_push("S5 quad fit");
     STAGE("k_fit_quads<0>");
     hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
                        d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
@@ -422,6 +448,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->class_lists.p + (size_t)4 * d->max_clusters, d->counters.p, 4, d->max_clusters, 0, d->points.p, d->dgray.p, g,
                        tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
 
+    range_pop();
+    range_push("S6-S7 edge refinement, homography, decode");
     STAGE("k_quad_compact");
     hipLaunchKernelGGL(k_quad_compact, dim3((d->max_clusters + 1023) / 1024), dim3(1024), 0, st, d->quads.p, d->counters.p, d->max_clusters,
                        d->quad_list.p);
@@ -433,6 +461,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL((g.channels == 1 ? k_decode<1> : k_decode<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
                        d->maxhamming, d->dets.p, d->max_dets, d->counters.p, d->quad_list.p);
 
+    range_pop();
+    range_push("S9 PnP, S8 de-duplication");
     if (cam) {
         STAGE("k_pnp_dets");
         const int lpw = pnp_lpw(d->nd_guess ? d->nd_guess : (size_t)20 * B);  // detections of the previous batch, else a guess
@@ -450,6 +480,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
         hipLaunchKernelGGL(k_det_gather, dim3((cap_f + 255) / 256, B), dim3(256), 0, st, d->dets.p, d->frame_idx.p, cap_f, d->frame_nkeep.p,
                            d->frame_off.p, d->out_det.p, d->out_pose.p, d->max_dets, cam ? 1 : 0);
     }
+    range_pop();
     if (d->profiling && d->nev <= MAX_STAGES) HIPCHK(hipEventRecord(d->ev[d->nev], st));
     HIPCHK(hipGetLastError());
     return ASL_OK;

@@ -125,6 +125,7 @@ for src, dst_name in ((tag + "_config3.json", tag + "_config3_detect_pnp_gn.json
                       (tag + "_gn_kernel_stats.csv", tag + "_gn_kernel_stats.csv"), (tag + "_pmc_gn.csv", tag + "_gn_mfma_counters.csv"),
                       (tag + "_exchange_n1.json", tag + "_bench_exchange_n1.json"), (tag + "_rehearse_gpus2.json", tag + "_bench_rehearse_gpus2_gloo.json"),
                       (tag + "_bench_configs2.json", tag + "_bench_configs2.json"), (tag + "_bench_configs4_n1.json", tag + "_bench_configs4_n1.json"),
-                      (tag + "_bench_configs4_rehearse_gpus2.json", tag + "_bench_configs4_rehearse_gpus2_gloo.json")):
+                      (tag + "_bench_configs4_rehearse_gpus2.json", tag + "_bench_configs4_rehearse_gpus2_gloo.json"),
+                      (tag + "_marker_trace.csv", tag + "_marker_trace.csv")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst_name))

@@ -34,3 +34,10 @@ python bench.py --workload configs2 --no-cpu-baseline > $O/${tag}_bench_configs2
 python bench.py --workload configs4 --no-cpu-baseline > $O/${tag}_bench_configs4_n1.json 2> /dev/null
 python bench.py --workload configs4 --gpus 2 --rehearse --steps 6 --warmup 2 --batch 64 --no-cpu-baseline > $O/${tag}_bench_configs4_rehearse_gpus2.json 2> /dev/null
 echo "multi-gpu legs done"
+# ROCTX ranges of the stage groups (host-side enqueue spans) next to the kernel trace, one short run
+cd /tmp
+rm -rf /tmp/prof_mk
+ASL_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --output-format csv -d /tmp/prof_mk -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --pipeline 1 > $O/${tag}_prof_mk.log 2>&1 || true
+ls /tmp/prof_mk/*/ > $O/${tag}_prof_mk_files.txt 2>&1 || true
+cp $(ls /tmp/prof_mk/*/*marker_api_trace.csv 2>/dev/null | head -1) $O/${tag}_marker_trace.csv 2>/dev/null || true
+echo "marker trace done"
