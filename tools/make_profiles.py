@@ -63,6 +63,13 @@ with open(os.path.join(P, tag + "_g_pmc_fetch_write_per_kernel.csv"), "w") as o:
     o.write("# rocprofv3 --pmc FETCH_SIZE (second run: --pmc WRITE_SIZE) -- python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline\n")
     o.write("# one launch = %d frames of 1280x720 BGR.  Counter unit: KB, average per launch.  gfx950: FETCH_SIZE counts 64 B per 128-B request on "
             "wide (16 B/lane) coalesced streams (x2 to compare with bytes); byte/dword gathers are uncalibrated, values are raw.\n" % B)
+    kd = [k for k in f if short(k) == "k_decimate_minmax"]
+    if kd:
+        known = 360 * 1280 * 3 * B / 1024.0  # KB: every second row of the 720p BGR frames, read exactly once
+        o.write("# calibration on a known byte count (MI355X_MICROARCH.md, HBM): k_decimate_minmax reads %.0f KB per launch by construction "
+                "(every second row of the input, once); FETCH_SIZE reports %.0f KB: x%.2f for its 16 + 4 + 1 byte loads at a 24-byte stride "
+                "(the guide's x2 holds for pure 16 B/lane streams); the other kernels' access widths are uncalibrated.\n"
+                % (known, f[kd[0]]["FETCH_SIZE"], known / f[kd[0]]["FETCH_SIZE"]))
     o.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,raw_bytes_per_frame(fetch+write)\n")
     for k in sorted(f):
         if not ours(k):
