@@ -74,38 +74,83 @@ def chain_initial_map(frames):
     return world, tags, cams
 
 
-def reseed_poses(cam_T, tag_T, obs_cam, obs_tag, obs_T, obs_corners, K, tag_size, fixed_tag, sweeps=2):
+def _padded_groups(key, n_groups):
+    """indices of the observations of every group (camera or tag), padded with -1: (n_groups, widest group)"""
+    key = np.asarray(key, dtype=np.int64)
+    order = np.argsort(key, kind="stable")
+    counts = np.bincount(key, minlength=n_groups)
+    width = int(counts.max()) if len(key) else 0
+    out = np.full((n_groups, max(width, 1)), -1, dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    col = np.arange(len(key)) - np.repeat(starts, counts)
+    out[key[order], col] = order
+    return out
+
+
+def _pick_best(current, cand_from_obs, cand_ok, rel_of, corners, obs_ok, K, tag_size):
+    """current (G,4,4); cand_from_obs (G,C,4,4) with validity cand_ok (G,C); rel_of(cand (G,C+1,4,4)) -> camera<-tag poses
+    (G,C+1,N,4,4) of every candidate against every observation of the group; corners (G,N,4,2), obs_ok (G,N).
+    Returns the candidate (current first, then in observation order) with the smallest total reprojection error."""
+    cand = np.concatenate([current[:, None], cand_from_obs], axis=1)
+    cost = reprojection_cost(rel_of(cand), corners[:, None], K, tag_size)               # (G, C+1, N)
+    cost = np.where(obs_ok[:, None, :], cost, 0.0).sum(axis=2)
+    cost[:, 1:] = np.where(cand_ok, cost[:, 1:], np.inf)
+    best = np.argmin(cost, axis=1)
+    return cand[np.arange(len(cand)), best]
+
+
+def reseed_poses(cam_T, tag_T, obs_cam, obs_tag, obs_T, obs_corners, K, tag_size, fixed_tag, sweeps=2, max_cand=None):
     """cam_T (P,4,4) world<-camera, tag_T (L,4,4) world<-tag, observations (camera index, tag index, PnP pose
     camera<-tag, corners 4x2).  Returns new (cam_T, tag_T).  The gauge is left free during the sweeps (a chain that
     started from a bad observation of the world tag is consistent everywhere except at that tag, and it is the world
-    tag that has to give way); at the end the map is re-expressed so that tag `fixed_tag` sits at the identity again."""
+    tag that has to give way); at the end the map is re-expressed so that tag `fixed_tag` sits at the identity again.
+    max_cand: a camera / tag tries only the poses implied by its max_cand largest observations (by corner area: the most
+    reliable single-view poses) instead of all of them; every candidate is still scored against ALL observations.
+    All cameras (then all tags) of a sweep are evaluated at once: they depend only on the other kind."""
     cam = np.array(cam_T, dtype=np.float64)
     tag = np.array(tag_T, dtype=np.float64)
     oc = np.asarray(obs_cam, dtype=np.int64)
     ot = np.asarray(obs_tag, dtype=np.int64)
     oT = np.asarray(obs_T, dtype=np.float64).reshape(-1, 4, 4)
     oC = np.asarray(obs_corners, dtype=np.float64).reshape(-1, 4, 2)
-    by_cam = [np.flatnonzero(oc == f) for f in range(len(cam))]
-    by_tag = [np.flatnonzero(ot == j) for j in range(len(tag))]
+    if len(oc) == 0:
+        return cam, tag
+    oTi = _inv(oT)
+    x, y = oC[:, :, 0], oC[:, :, 1]
+    area = 0.5 * np.abs((x * np.roll(y, -1, axis=1) - y * np.roll(x, -1, axis=1)).sum(axis=1))
+
+    def groups(key, n):
+        idx = _padded_groups(key, n)
+        ok = idx >= 0
+        if max_cand is not None and idx.shape[1] > max_cand:
+            a = np.where(ok, area[np.maximum(idx, 0)], -1.0)
+            sel = np.sort(np.argsort(-a, axis=1, kind="stable")[:, :max_cand], axis=1)     # the largest, in observation order
+            cidx = np.take_along_axis(idx, sel, axis=1)
+        else:
+            cidx = idx
+        return np.maximum(idx, 0), ok, np.maximum(cidx, 0), cidx >= 0
+
+    ci, ci_ok, cc, cc_ok = groups(oc, len(cam))
+    ti, ti_ok, tc, tc_ok = groups(ot, len(tag))
     for _ in range(sweeps):
-        for f, idx in enumerate(by_cam):
-            if len(idx) == 0:
-                continue
-            cand = np.concatenate([cam[f][None], tag[ot[idx]] @ _inv(oT[idx])])       # world<-camera candidates
-            rel = _inv(cand)[:, None] @ tag[ot[idx]][None]                            # (cand, obs) camera<-tag
-            cost = reprojection_cost(rel, oC[idx][None], K, tag_size).sum(axis=1)
-            cam[f] = cand[int(np.argmin(cost))]
-        for j, idx in enumerate(by_tag):
-            if len(idx) == 0:
-                continue
-            cand = np.concatenate([tag[j][None], cam[oc[idx]] @ oT[idx]])              # world<-tag candidates
-            rel = _inv(cam[oc[idx]])[None] @ cand[:, None]                            # (cand, obs)
-            cost = reprojection_cost(rel, oC[idx][None], K, tag_size).sum(axis=1)
-            tag[j] = cand[int(np.argmin(cost))]
+        has = ci_ok.any(axis=1)
+        new = _pick_best(cam, tag[ot[cc]] @ oTi[cc], cc_ok, lambda cand: _inv(cand)[:, :, None] @ tag[ot[ci]][:, None], oC[ci], ci_ok, K, tag_size)
+        cam = np.where(has[:, None, None], new, cam)
+        has = ti_ok.any(axis=1)
+        new = _pick_best(tag, cam[oc[tc]] @ oT[tc], tc_ok, lambda cand: _inv(cam[oc[ti]])[:, None] @ cand[:, :, None], oC[ti], ti_ok, K, tag_size)
+        tag = np.where(has[:, None, None], new, tag)
     M = _inv(tag[fixed_tag])
     cam, tag = M[None] @ cam, M[None] @ tag
     tag[fixed_tag] = np.eye(4)
     return cam, tag
+
+
+def behind_camera(cam_T, tag_T, obs_cam, obs_tag, tag_size, margin=1e-6):
+    """per observation: does any corner of the tag, as the map has it, lie on or behind the camera's image plane?"""
+    X = _corners_obj(tag_size)
+    rel = _inv(np.asarray(cam_T, dtype=np.float64))[np.asarray(obs_cam, dtype=np.int64)] @ np.asarray(tag_T, dtype=np.float64)[np.asarray(obs_tag, dtype=np.int64)]
+    z = np.einsum('nj,kj->nk', rel[:, 2, :], X)
+    return (z <= margin).any(axis=1)
 
 
 def _exp_so3(w):

@@ -455,7 +455,8 @@ def main():
                 rec = rec[(rec["flags"] & 3) == 3]
                 if len(rec) and not np.isnan(poses[s_, f_]).any():
                     cams.append(poses[s_, f_])
-                    obs.append([(int(i), c.reshape(4, 2).astype(np.float64)) for i, c in zip(rec["id"], rec["corners"])])
+                    # (id, corners, single-view PnP pose): the poses let the solve pick consistent starting values
+                    obs.append([(int(i), c.reshape(4, 2).astype(np.float64), T_) for i, c, T_ in zip(rec["id"], rec["corners"], adist._full(rec["T"]))])
             if cams:
                 state["gn_last"] = slam.optimize_window(cams, obs, iters=2, backend=detectors[k])
                 serial["gn_runs"] += 1
@@ -487,6 +488,7 @@ def main():
         return out
 
     kernel_ms = {}
+    lm_bad = False
     for k in range(P):  # set-up, not a step: first use allocates each workspace (hipMalloc of several GB)
         detectors[k].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[k].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
         detectors[k].collect(max_per_frame=MAXDET)
@@ -642,8 +644,19 @@ def main():
             line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(distinct[:nchk], K)
         print(json.dumps(line))
+        lm = state.get("gn_last")
+        if xchg and lm is not None:
+            # a pose-graph solve inside the timed region must have solved something: a start behind the image plane or a
+            # diverged step shows as a cost of 1e12 and more per observation
+            per_obs = lm["cost"] / max(lm["observations"], 1)
+            if not (lm["cost"] <= lm["cost0"] and per_obs < 50.0):
+                sys.stderr.write("bench.py: the pose-graph LM of the last window is unhealthy (cost0 %.3g -> cost %.3g over %d observations)\n"
+                                 % (lm["cost0"], lm["cost"], lm["observations"]))
+                lm_bad = True
     if use_pg:
         dist.destroy_process_group()
+    if lm_bad:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
