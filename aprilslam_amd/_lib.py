@@ -340,7 +340,7 @@ class Detector:
 
     # -- introspection for the parity tests ------------------------------------------------
     def debug_counters(self):
-        buf = np.zeros(16, dtype=np.int64)
+        buf = np.zeros(18, dtype=np.int64)
         n = C.c_size_t()
         check(self._L.asl_debug_fetch(self._h, 5, buf.ctypes.data, buf.nbytes, C.byref(n)))
         return buf

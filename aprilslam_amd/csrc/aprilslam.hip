@@ -92,7 +92,7 @@ struct asl_detector {
     DevBuf<unsigned int> dbg_labels;    // asl_debug_fetch only: per-pixel labels
     DevBuf<unsigned int> parent, sizes;
     DevBuf<unsigned long long> hkeys, points, rootmask, wmask, bmask;
-    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, quad_list;
+    DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, dense_seg, quad_list;
     DevBuf<unsigned long long> stage_rec;
     unsigned int stage_cap = 0;  // staged points per frame
     DevBuf<unsigned long long> slot_cluster;  // per hash slot: offset | count << 32 of its cluster's segment
@@ -208,7 +208,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
-    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->wmask.release(); d->bmask.release();
+    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->dense_seg.release(); d->wmask.release(); d->bmask.release();
     d->dbg_thresh.release(); d->dbg_labels.release();
     d->frame_ndets.release(); d->frame_idx.release(); d->frame_nkeep.release(); d->frame_off.release(); d->out_det.release(); d->out_pose.release();
     if (d->host_pose) (void)hipHostFree(d->host_pose);
@@ -334,6 +334,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->stage_pos.ensure((size_t)B * d->stage_cap);
     bad |= d->frame_cursor.ensure(B);
     bad |= d->dense_tiles.ensure(B * count_tiles(g));
+    bad |= d->dense_seg.ensure(B * (size_t)seg_nwx(g) * (size_t)((g.sh + SEG_TH - 1) / SEG_TH));
     bad |= d->scratch.ensure((size_t)d->max_points * 8);
     bad |= d->dets.ensure(d->max_dets);
     bad |= d->frame_ndets.ensure(B);
@@ -385,10 +386,16 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     const size_t nwords = (size_t)B * g.sh * nwx;
     STAGE("k_tile_cut");
     if (g.tw > 0 && g.th > 0)
-        hipLaunchKernelGGL(k_tile_cut, dim3((g.tw + 63) / 64, (g.th + 3) / 4, B), dim3(64, 4), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
+        hipLaunchKernelGGL(k_tile_cut, dim3((((g.tw + 3) / 4) * g.th + 255) / 256, B), dim3(256), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
     STAGE("k_seg_tile");
-    hipLaunchKernelGGL(k_seg_tile, dim3((nwx * ((g.sh + SEG_TH - 1) / SEG_TH) + SEG_TILE_WAVES - 1) / SEG_TILE_WAVES, 1, B), dim3(64 * SEG_TILE_WAVES), 0, st, d->dgray.p, d->tcut.p, g, nwx,
-                       d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->counters.p);
+    {
+        const int ntiles = nwx * ((g.sh + SEG_TH - 1) / SEG_TH);
+        hipLaunchKernelGGL(k_seg_tile, dim3(ntiles, 1, B), dim3(64), 0, st, d->dgray.p, d->tcut.p, g, nwx,
+                           d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->dense_seg.p, d->counters.p);
+        // tiles with more runs or links than the common launch's tables hold (none in ordinary frames: the launch finds an empty list)
+        hipLaunchKernelGGL(k_seg_tile_dense, dim3(1024), dim3(64), 0, st, g, nwx, ntiles, d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p,
+                           d->rootmask.p, d->dense_seg.p, d->counters.p);
+    }
     STAGE("k_seg_border");
     {
         const size_t nseams = nwx > 1 ? (size_t)B * g.sh * (nwx - 1) : 0;
@@ -891,14 +898,15 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
         return ASL_OK;
     }
     case 5: {
-        if (bytes < sizeof(long long) * 16) return fail(ASL_EINVAL, "dst too small");
+        if (bytes < sizeof(long long) * 18) return fail(ASL_EINVAL, "dst too small");
         long long *o = (long long *)dst;
         o[0] = g.nframes; o[1] = g.sw; o[2] = g.sh;
         o[3] = d->last_counters[CNT_NCLUSTERS]; o[4] = d->last_counters[CNT_NPOINTS]; o[5] = d->last_counters[CNT_NQUADS];
         o[6] = d->last_counters[CNT_NDETS]; o[7] = d->nslots; o[8] = d->max_clusters; o[9] = d->max_points; o[10] = d->max_dets;
         o[11] = d->last_counters[CNT_OVERFLOW_HASH]; o[12] = d->last_counters[CNT_OVERFLOW_CLUSTERS];
         o[13] = d->last_counters[CNT_OVERFLOW_POINTS]; o[14] = d->last_counters[CNT_OVERFLOW_DETS]; o[15] = d->last_counters[CNT_CLASS0];
-        *n_items = 16;
+        o[16] = d->last_counters[CNT_DENSE_TILES]; o[17] = d->last_counters[CNT_DENSE_SEG];  // tiles that took the dense launches
+        *n_items = 18;
         return ASL_OK;
     }
     default:
@@ -910,10 +918,15 @@ extern "C" int asl_debug_phase_cycles(asl_detector *d, unsigned long long *out64
 {
     if (!d || !out64) return fail(ASL_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(d->device));
-    HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 64));
+    std::vector<unsigned long long> all((size_t)64 * PHASE_SPREAD);
+    HIPCHK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * all.size()));
+    for (int i = 0; i < 64; i++) {
+        out64[i] = 0;
+        for (int k = 0; k < PHASE_SPREAD; k++) out64[i] += all[(size_t)i * PHASE_SPREAD + k];
+    }
     if (reset) {
-        unsigned long long z[64] = {0};
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z));
+        std::fill(all.begin(), all.end(), 0ull);
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), all.data(), sizeof(unsigned long long) * all.size()));
     }
     return ASL_OK;
 }

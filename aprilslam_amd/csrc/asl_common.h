@@ -109,6 +109,7 @@ enum {
     CNT_UF_GUARD,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
     CNT_NKEEP,        // detections that survive the de-duplication (what the caller receives)
     CNT_DEDUP_LIMIT,  // frames with more detections than the de-duplication sorts (fails the batch loudly)
+    CNT_DENSE_SEG,    // tiles of the labelling pass with more runs or links than its LDS tables hold (k_seg_tile_dense takes them)
     CNT__N = 24
 };
 
@@ -121,7 +122,8 @@ __device__ __forceinline__ bool batch_poisoned(const long long *counters)
 
 // Diagnostic build only (-DASL_PHASE_TIMING): per-phase shader-clock sums, one stamp per block.
 // The shipped library compiles these to nothing.
-__device__ unsigned long long g_phase_cycles[64];
+#define PHASE_SPREAD 512  /* copies of every counter (one address sustains ~90 atomics/us); the host adds them up */
+__device__ unsigned long long g_phase_cycles[64 * PHASE_SPREAD];
 #ifdef ASL_PHASE_TIMING
 // stamps are summed in LDS by thread 0 and leave with one atomic per phase when the workgroup ends: an atomic per
 // stamp would queue behind the other workgroups' (one address sustains ~90 atomics/us) and the next global load of
@@ -140,16 +142,18 @@ __device__ unsigned long long g_phase_cycles[64];
             ph_t__ = now__;                                                           \
         }                                                                             \
     } while (0)
+#define PHASE_COUNT(k, v) do { if (threadIdx.x == 0 && threadIdx.y == 0) ph_s__[(k) & 15] += (unsigned long long)(v); } while (0)
 #define PHASE_FLUSH(base)                                                             \
     do {                                                                              \
         if (threadIdx.x == 0 && threadIdx.y == 0)                                     \
             for (int ph_i__ = 0; ph_i__ < 16; ph_i__++)                               \
-                if (ph_s__[ph_i__]) atomicAdd(&g_phase_cycles[(base) + ph_i__], ph_s__[ph_i__]); \
+                if (ph_s__[ph_i__]) atomicAdd(&g_phase_cycles[((base) + ph_i__) * PHASE_SPREAD + ((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (PHASE_SPREAD - 1))], ph_s__[ph_i__]); \
     } while (0)
 #else
 #define PHASE_DECL() do {} while (0)
 #define PHASE_INIT() do {} while (0)
 #define PHASE(k) do {} while (0)
+#define PHASE_COUNT(k, v) do {} while (0)
 #define PHASE_FLUSH(base) do {} while (0)
 #endif
 

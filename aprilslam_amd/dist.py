@@ -55,6 +55,44 @@ def pack_observations(dets, poses, n_per_frame, max_tags):
     return out
 
 
+class _Roctx:
+    """ROCTX ranges for `rocprofv3 --marker-trace` (SURVEY.md 8d asks for one around the all-gather): ASL_ROCTX=1 loads the
+    marker library the way libaprilslam.so does for its stage groups; without it push / pop do nothing."""
+
+    def __init__(self):
+        self._push = self._pop = None
+        import os
+        if os.environ.get("ASL_ROCTX", "0") in ("", "0"):
+            return
+        import ctypes
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                self._push, self._pop = lib.roctxRangePushA, lib.roctxRangePop
+                return
+            except (OSError, AttributeError):
+                continue
+
+    def push(self, name):
+        if self._push:
+            self._push(name.encode())
+
+    def pop(self):
+        if self._pop:
+            self._pop()
+
+
+_roctx = None
+
+
+def roctx():
+    global _roctx
+    if _roctx is None:
+        _roctx = _Roctx()
+    return _roctx
+
+
 def all_gather_observations(local_obs):
     """local_obs: (n_frames, max_tags) asl_obs records as a numpy structured array or as a torch uint8 tensor
     (n_frames, max_tags, 136) on the device.  Returns the same kind with a leading `world` axis, identical on every
@@ -70,7 +108,9 @@ def all_gather_observations(local_obs):
     else:
         world = dist.get_world_size()
         flat = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+        roctx().push("all-gather of observation records")
         dist.all_gather_into_tensor(flat, t.contiguous().view(-1))  # flat in, flat out: the form every backend accepts
+        roctx().pop()
         out = flat.view((world,) + tuple(t.shape))
     if is_np:
         return out.numpy().view(OBS_DTYPE).reshape(out.shape[:-1])

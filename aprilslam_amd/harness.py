@@ -112,7 +112,9 @@ class GroundTruth:
 
 
 class HeadlessSimulation:
-    def __init__(self, config, logger, output_dir=None, device=0, slam=None):
+    def __init__(self, config, logger, output_dir=None, device=0, slam=None, textures=None):
+        """textures: {tag id: (h, w, 3) uint8} tag images as the reference's renderer uploads them (renderer.py:160-171:
+        assets/tags/tag<id>.png); None = the synthetic 40-texel-per-cell bitmaps of aprilslam_amd.synth."""
         if isinstance(config, str):
             with open(config) as f:
                 config = json.load(f)
@@ -128,6 +130,7 @@ class HeadlessSimulation:
         params = {"camera_matrix": self.camera_matrix, "dist_coeffs": np.zeros((4, 1))}
         self.slam = slam if slam is not None else SLAM(logger, params, tag_size=self.tag_size_inner, device=device)
         self.ground_truth = GroundTruth(self.tags)
+        self.textures = textures
         self.rows, self.error_rows, self.covariance_rows = [], [], []
         self.start_time = time.time()
         self._files, self._writer, self._error_writer, self._covariance_writer = [], None, None, None
@@ -147,7 +150,7 @@ class HeadlessSimulation:
         """One iteration of the reference's main loop.  The reference's ground truth ignores camera rotation
         (ground_truth.py:146-188), so error columns are only meaningful for camera_rotation == 0."""
         frame, _ = synth.render_frame(self.width, self.height, self.tags, self.tag_size_outer, cam_position=camera_position,
-                                      cam_rotation_deg=camera_rotation, fov_y_deg=self.config.get("fov_y", 45))
+                                      cam_rotation_deg=camera_rotation, fov_y_deg=self.config.get("fov_y", 45), textures=self.textures)
         detections = self.slam.detect(frame)
         for d in detections:
             self.slam.get_pose(d)

@@ -149,9 +149,30 @@ def pose_rmse_vs_ground_truth(dets, poses, npf, gts):
             "note": "vs analytic ground truth of the synthetic renderer; includes the detector's corner noise"}
 
 
+CPU_FLAGS = "-O3 -march=native -ffp-contract=off (oracle/Makefile: native)"
+
+
+def build_native_oracle():
+    """The CPU baseline's own build of oracle/ (-O3 -march=native), made on THIS host, outside the
+    tree; oracle_lib loads it through ASO_SO.  Falls back to the -O2 parity build (and says so) if the compiler is missing."""
+    import subprocess
+    import tempfile
+    global CPU_FLAGS
+    if os.environ.get("ASO_SO"):
+        return
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "NATIVE_OUT=" + out],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["ASO_SO"] = out  # inherited by the worker processes of the all-cores leg
+    except (OSError, subprocess.CalledProcessError):
+        CPU_FLAGS = "-O2 -ffp-contract=off (oracle/liboracle.so; the native build failed on this host)"
+
+
 def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
     """The CPU restatement (oracle/, 1 thread) timed on this host on a bounded sample of the same workload.
     With gpu=(dets, poses, npf) of the same frames it also reports how far the GPU results are from it."""
+    build_native_oracle()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from aprilslam_amd.families import get_family
@@ -168,7 +189,7 @@ def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
             break
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp, 1 thread, %.1f s" % (n, dt)}
+           "sample": "%d frames of the same %dx%dx%d-tag stream, oracle/ detect_bgr + solve_pnp built %s, 1 thread, %.1f s" % (n, W, H, NTAGS, CPU_FLAGS, dt)}
     if gpu is not None:
         dets, poses, npf = gpu
         start, ids_equal, dcorner, dtr, drot = 0, True, 0.0, [], []
@@ -192,11 +213,15 @@ def cpu_baseline(frames, K, budget_s=12.0, gpu=None):
     return out
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, timeout_s=1500.0):
     """--gpus N without a launcher: N fresh children, one per GPU, started BEFORE this process touches the GPU; rank 0's
-    stdout (the JSON line) is passed through."""
+    stdout (the JSON line) is passed through, every rank's stderr (and the other ranks' stdout) goes to this process's
+    stderr.  All children are watched: when one of them fails, or the time runs out, the others are terminated (a rank
+    that dies before its first collective would otherwise leave its peers waiting in RCCL until their own timeout) and
+    the exit code is non-zero."""
     import socket
     import subprocess
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -205,12 +230,35 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rc = [p.wait() for p in procs]
-    sys.stdout.write(out)
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0, failed = time.monotonic(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+        elif time.monotonic() - t0 > timeout_s:
+            failed = "no result after %.0f s" % timeout_s
+        if failed or all(c is not None for c in codes):
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: %s; the other ranks were stopped\n" % failed)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode(errors="replace"))
     sys.stdout.flush()
-    return max(abs(c) for c in rc)
+    return 1 if failed else 0
 
 
 def _cpu_worker(args):
@@ -252,7 +300,7 @@ def cpu_baseline_all_cores(frames, K, budget_s=10.0):
     total = sum(r[0] for r in res)
     rate = sum(r[0] / r[1] for r in res)
     return {"value": rate, "unit": "frames/s", "cores": cores, "cpu": model, "kind": "port",
-            "sample": "%d frames in %.1f s wall (%d processes x %.0f s of the same 1280x720x20-tag stream, oracle/liboracle.so detect_bgr + solve_pnp)" % (total, wall, cores, budget_s)}
+            "sample": "%d frames in %.1f s wall (%d processes x %.0f s of the same %dx%dx%d-tag stream, oracle/ detect_bgr + solve_pnp built %s)" % (total, wall, cores, budget_s, W, H, NTAGS, CPU_FLAGS)}
 
 
 def h2d_included(det, d_frames, K, n=256, reps=3):
@@ -273,6 +321,66 @@ def h2d_included(det, d_frames, K, n=256, reps=3):
             "note": "asl_detect_batch_pose_u8 from page-locked host frames: PCIe copy + the same batch, synchronous"}
 
 
+def project_serial_term(det, d_frames, K, dev, max_tags, world=8, reps=5):
+    """The serial (Amdahl) part of a `world`-GPU step, measured on ONE GPU: this rank's packed observation block is
+    replicated `world` times on the device (what the all-gather would deliver, minus the transfer itself), then the
+    per-step work every rank does on the gathered block runs on it as in the multi-GPU step: asl_graph_frames_device over
+    world x B frames, the read-back of its results, and dist.apply_block on the host.  A PROJECTION: the collective's own
+    time (3.3 MB per rank over xGMI) is not in it."""
+    import torch
+    from aprilslam_amd import dist as adist
+    from aprilslam_amd.slam import SLAM
+
+    class _Log:
+        def info(self, m):
+            pass
+    B = d_frames.shape[0]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    obs = torch.empty((B, max_tags, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    det.submit_device(d_frames.data_ptr(), B, 3, W, H, stream=st, K=K, dist=np.zeros(4), tag_size=TAG_INNER)
+    det.pack_observations_device(obs.data_ptr(), max_tags, stream=st)
+    det.collect_view()
+    block = obs[None].repeat(world, 1, 1, 1).contiguous()
+    pose = torch.zeros((world * B, 16), dtype=torch.float64, device=dev)
+    status = torch.zeros(world * B, dtype=torch.uint8, device=dev)
+    last = torch.zeros(adist.MAX_IDS, dtype=torch.int32, device=dev)
+    picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    h_pose, h_status = torch.zeros((world * B, 16), dtype=torch.float64).pin_memory(), torch.zeros(world * B, dtype=torch.uint8).pin_memory()
+    h_last = torch.zeros(adist.MAX_IDS, dtype=torch.int32).pin_memory()
+    h_picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    h_tail = torch.zeros((world, max_tags, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    slam = SLAM(_Log(), {"camera_matrix": K, "dist_coeffs": np.zeros(4)}, tag_size=TAG_INNER, detector=object())
+    t_dev, t_host, nseq = [], [], 0
+    for it in range(reps + 1):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res = None
+        if slam.coordinate_id != -1:
+            last.zero_()
+            det.graph_frames_device(block.data_ptr(), world, B, max_tags, slam.coordinate_id, pose.data_ptr(), status.data_ptr(), last.data_ptr(),
+                                    adist.MAX_IDS, picks_ptr=picks.data_ptr(), stream=st)
+            h_pose.copy_(pose, non_blocking=True); h_status.copy_(status, non_blocking=True)
+            h_last.copy_(last, non_blocking=True); h_picks.copy_(picks, non_blocking=True)
+            h_tail.copy_(block[:, B - 1], non_blocking=True)
+            torch.cuda.synchronize(dev)
+            res = (h_pose.numpy(), h_status.numpy(), h_last.numpy().view(np.uint32))
+        t1 = time.perf_counter()
+        blk = adist.ObsBlock(block)
+        if res is not None:
+            pk = h_picks.numpy().reshape(-1).view(adist.OBS_DTYPE)
+            tail = h_tail.numpy().reshape(-1).view(adist.OBS_DTYPE).reshape(world, max_tags)
+            _, n = adist.apply_block(slam, blk, res, picks=pk, tail=tail)
+        else:
+            _, n = adist.apply_block(slam, blk)
+        t2 = time.perf_counter()
+        if it > 0:  # the first pass starts without a world tag (sequential start-up) and allocates
+            t_dev.append(t1 - t0); t_host.append(t2 - t1); nseq += n
+    return {"world": world, "frames_per_step": world * B, "graph_kernel_and_readback_ms": 1e3 * float(np.mean(t_dev)),
+            "graph_update_host_ms": 1e3 * float(np.mean(t_host)), "serial_ms_per_step": 1e3 * float(np.mean(t_dev) + np.mean(t_host)),
+            "frames_through_sequential_update": nseq,
+            "note": "PROJECTED on one GPU: this rank's block replicated %d x on the device, graph kernel + read-back + host apply of a %d-GPU step; the all-gather itself is not included" % (world, world)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +391,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (tiled to --batch); 0 = every frame of the batch is distinct")
     ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="only the warm-up, the timed steps and the one isolated batch: no h2d / render / both-minima / projection / CPU legs (for rocprofv3 passes: every detector launch then has the full batch size)")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
     ap.add_argument("--max-tags", type=int, default=0, help="tag slots per frame in the exchanged observation records (0 = tags per frame + 4)")
     ap.add_argument("--gn-every", type=int, default=-1, help="pose-graph LM on a window every this many steps of the exchange (0 = never, -1 = the workload's default)")
@@ -616,7 +725,7 @@ def main():
         }
         nchk = NCHK
         line["pose_rmse"] = pose_rmse_vs_ground_truth(last[0], last[1], last[2], distinct_gt[:nchk])
-        if world == 1:
+        if world == 1 and not args.timed_only:
             # the same frames with the better of the two planar poses per tag (not what the reference computes: reported apart)
             detectors[0].set_pnp_both_minima(True)
             detectors[0].submit_device(d_frames.data_ptr(), B, 3, W, H, stream=streams[0].cuda_stream, K=K, dist=zeros4, tag_size=TAG_INNER)
@@ -625,6 +734,7 @@ def main():
             line["pose_rmse_both_minima"] = pose_rmse_vs_ground_truth(alt[0], alt[1], alt[2], distinct_gt[:nchk])
             line["pose_rmse_both_minima"]["k_pnp_dets_ms"] = detectors[0].stage_times().get("k_pnp_dets")
             line["h2d_included"] = h2d_included(detectors[0], d_frames, K)
+            line["multi_gpu_projection"] = project_serial_term(detectors[0], d_frames, K, dev, MT)
             if ndist == B:
                 # the producer inside the step: every step first renders its B frames on the device, then detects
                 def rstep(k_):
@@ -640,7 +750,7 @@ def main():
                 tr = time.perf_counter() - tr0
                 line["render_included"] = {"value": B * nrs / tr, "unit": "frames/s", "steps": nrs, "ms_per_step": 1e3 * tr / nrs,
                                            "note": "asl_render_frames_device (k_render) of the step's 1024 frames + the same batch, one workspace, synchronous; not the headline value"}
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+        if not args.no_cpu_baseline and not args.timed_only and world == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(distinct[:nchk], K, gpu=last)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(distinct[:nchk], K)
         print(json.dumps(line))

@@ -209,7 +209,7 @@ int asl_render_frames_device(asl_detector *det, void *d_frames, int n_frames, in
    what: 0 = decimated gray (u8, B*sh*sw)     1 = threshold image (u8, B*sh*sw)
          2 = component labels (u32, B*sh*sw)  3 = component sizes by label (u32, B*sh*sw)
          4 = candidate quads (asl_debug_quad, count via *n_items)
-         5 = stage counters (int64[16]: frames, sw, sh, clusters, points, quads, detections, ...)
+         5 = stage counters (int64[18]: frames, sw, sh, clusters, points, quads, detections, ..., tiles of the two dense launches)
    bytes = capacity of dst; *n_items = number of elements written. */
 typedef struct {
     double p[4][2]; /* decimated-image pixel coordinates, before the full-resolution rescale */

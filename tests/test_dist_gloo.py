@@ -202,3 +202,35 @@ def test_segmented_update_randomised():
         assert np.array_equal(a.graph.estimated_pose, b.graph.estimated_pose) and a.visible_tags == b.visible_tags, blk_i
     assert bulk_frames > 0.5 * 40 * world * n_frames  # most frames did take the bulk path
     assert a.coordinate_id == 0
+
+
+def test_spawn_ranks_stops_the_peers_of_a_failed_rank(tmp_path, capfd):
+    """bench.py --gpus N starts its own ranks: rank 0's stdout is passed through, and a rank that dies takes the others
+    down with a non-zero exit code instead of leaving them waiting in a collective."""
+    import textwrap
+    import time
+    import bench
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(textwrap.dedent('''
+        import os, sys, time
+        r = int(os.environ["RANK"])
+        assert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        if "--fail" in sys.argv and r == 2:
+            sys.exit(7)
+        if r == 0:
+            time.sleep(60 if "--fail" in sys.argv else 0.2)
+            print('{"n_gpus": 3}')
+        elif "--fail" in sys.argv:
+            time.sleep(60)
+    '''))
+    real = bench.__file__
+    bench.__file__ = str(fake)
+    try:
+        assert bench.spawn_ranks(3, []) == 0
+        assert '{"n_gpus": 3}' in capfd.readouterr().out
+        t0 = time.monotonic()
+        assert bench.spawn_ranks(3, ["--fail"]) == 1
+        assert time.monotonic() - t0 < 20
+        assert "rank 2 exited with code 7" in capfd.readouterr().err
+    finally:
+        bench.__file__ = real

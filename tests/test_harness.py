@@ -91,6 +91,76 @@ def test_node_analysis_rows_without_a_gpu(tmp_path):
         assert abs(float(r[-2])) < 1e-9 and abs(float(r[-3])) < 1e-9 and float(r[0]) == 1
 
 
+class _OracleDetector:
+    """The TagDetector call surface (detect / get_pose, tag_detector.py:23-52) answered by the CPU oracle: lets the
+    harness class run its loop in the CPU suite (test infrastructure; the product's TagDetector has no CPU path)."""
+
+    def __init__(self, K, tag_size):
+        import oracle_lib as O
+        from aprilslam_amd.families import get_family
+        self.O, self.fam, self.K, self.tag_size = O, get_family(), K, tag_size
+
+    def detect(self, image):
+        return [{"id": d["id"], "lb-rb-rt-lt": d["corners"]} for d in self.O.detect_bgr(image, self.fam)]
+
+    def get_pose(self, detection):
+        rv, tv, T, ok = self.O.solve_pnp(np.asarray(detection["lb-rb-rt-lt"])[None], self.K, np.zeros(4), self.tag_size)
+        return bool(ok[0]), rv[0].reshape(3, 1), tv[0].reshape(3, 1), T[0]
+
+
+def _run_reference_csv(sim, tmp_path):
+    """HeadlessSimulation over the camera positions of the reference's committed run; its 17-column CSV, row by row,
+    against the reference's own (data/csv/slam_clustered_data.csv -> tests/golden/reference_trajectory.json).
+    Bars as in tests/golden_scene.py (position / Euler angles of the estimate against the reference's estimate); the
+    ground-truth columns are formulas and must agree to rounding."""
+    import contextlib
+    import csv
+    import io
+    import golden_scene as G
+    rows = G.TRAJ[:G.N_TAG0_VISIBLE]
+    with contextlib.redirect_stdout(io.StringIO()):
+        for r in rows:
+            assert sim.step(np.array(G.camera_position(r))) is not None
+    sim.close()
+    got = list(csv.reader(open(tmp_path / "slam_simulation_data.csv")))
+    assert got[0] == harness.MAIN_CSV_HEADER and len(got) == 1 + len(rows)
+    col = {n: i for i, n in enumerate(harness.MAIN_CSV_HEADER)}
+    for k, (r, g) in enumerate(zip(rows, got[1:])):
+        v = {n: float(g[i]) for n, i in col.items()}
+        assert int(v["Number_of_Nodes"]) == r["num_nodes"], k
+        est = np.array([v["Est_X"], v["Est_Y"], v["Est_Z"]]); rpy = np.array([v["Est_Roll"], v["Est_Pitch"], v["Est_Yaw"]])
+        d = np.linalg.norm(est - np.array(r["est_xyz"])); da = np.abs(G.wrap(rpy - np.array(r["est_rpy"]))).max()
+        lead = k < G.LEAD_ROWS
+        assert d < (G.LEAD_POS if lead else G.ALL_POS) and da < (G.LEAD_RPY if lead else G.ALL_RPY), (k, d, da)
+        assert np.abs(np.array([v["GT_X"], v["GT_Y"], v["GT_Z"]]) - np.array(r["gt_xyz"])).max() < 1e-9, k
+        assert np.abs(G.wrap(np.array([v["GT_Roll"], v["GT_Pitch"], v["GT_Yaw"]]) - np.array(r["gt_rpy"]))).max() < 1e-9, k
+        # the two error columns are distances of the estimate from ground truth: they move by at most the estimate's own distance
+        assert abs(v["Translation_Difference"] - r["translation_difference"]) <= d + 1e-9, k
+        assert abs(v["Rotation_Difference"] - r["rotation_difference"]) < 3e-3, k
+    origin = {n: float(got[1][i]) for n, i in col.items()}
+    assert abs(origin["Translation_Difference"] - 0.0203475) < 0.015  # slam_clustered_data.csv:2
+
+
+def test_headless_run_reproduces_the_references_csv_with_the_oracle(tmp_path):
+    import logging
+    import golden_scene as G
+    from aprilslam_amd.slam import SLAM
+    sc = synth.default_scene()
+    K = synth.camera_matrix(sc["display_width"], sc["display_height"], sc["fov_y"])
+    tag_size = sc["tag_size_inner"] * sc["size_scale"]
+    slam = SLAM(G.Log(), {"camera_matrix": K, "dist_coeffs": np.zeros((4, 1))}, tag_size=tag_size, detector=_OracleDetector(K, tag_size))
+    _run_reference_csv(harness.HeadlessSimulation(sc, logging, output_dir=str(tmp_path), slam=slam, textures=G.textures()), tmp_path)
+
+
+@pytest.mark.gpu
+def test_headless_run_reproduces_the_references_csv(tmp_path):
+    """the harness class itself on the GPU path (TagDetector -> libaprilslam.so), same rows, same bars"""
+    import logging
+    import golden_scene as G
+    sim = harness.HeadlessSimulation(synth.default_scene(), G.Log(), output_dir=str(tmp_path), textures=G.textures())
+    _run_reference_csv(sim, tmp_path)
+
+
 @pytest.mark.gpu
 def test_headless_run_default_scene(tmp_path):
     import csv
@@ -102,8 +172,9 @@ def test_headless_run_default_scene(tmp_path):
         assert out is not None and 0 in out["ids"]
     sim.close()
     st = sim.statistics()
-    # the reference's own logged run has translation RMSE 1.8 units / rotation RMSE 0.0071 on this scene
-    assert st["frames"] == 6 and st["translation_rmse_units"] < 1.8 and st["rotation_fro_rmse"] < 0.05
+    # views that are not pixel-aligned: the detector is accurate there (test_default_scene_generic_view_is_accurate holds
+    # a single view to 0.05 units / 2e-3); the reference's own logged run, all pixel-aligned, has RMSE 1.8 units / 0.0071
+    assert st["frames"] == 6 and st["translation_rmse_units"] < 0.08 and st["rotation_fro_rmse"] < 2.5e-3, st  # observed 0.036 / 9.4e-4
     rows = list(csv.reader(open(tmp_path / "slam_simulation_data.csv")))
     assert rows[0] == harness.MAIN_CSV_HEADER and len(rows) == 7 and len(rows[1]) == 17
     erows = list(csv.reader(open(tmp_path / "error_analysis.csv")))
