@@ -19,6 +19,7 @@
 #include "k_cc.inc"
 #include "k_cluster.inc"
 #include "k_seg.inc"
+#include "k_xchg.inc"
 #include "k_quad.inc"
 #include "k_decode.inc"
 #include "k_pnp.inc"
