@@ -95,6 +95,7 @@ struct asl_detector {
     DevBuf<unsigned long long> hkeys, points, rootmask, wmask, bmask;
     DevBuf<unsigned int> hcounts, class_lists, stage_pos, frame_cursor, dense_tiles, dense_seg, quad_list;
     DevBuf<unsigned long long> stage_rec;
+    DevBuf<uint4> seg_edges;  // per labelling tile: its first / last pixel column, a bit per row and colour
     unsigned int stage_cap = 0;  // staged points per frame
     DevBuf<unsigned long long> slot_cluster;  // per hash slot: offset | count << 32 of its cluster's segment
     DevBuf<ClusterRec> clusters;
@@ -110,6 +111,8 @@ struct asl_detector {
     DevBuf<double> pnp_out;
     DevBuf<uint8_t> pnp_ok;
     GnWorkspace gn;
+    hipStream_t copy_stream = nullptr, host_stream = nullptr;  // host frames: transfers and the chunks' kernels (detect_host_frames)
+    std::vector<hipEvent_t> copy_done;
     hipStream_t aux_stream = nullptr;  // highest priority, for the small latency-bound jobs next to a running batch (pose-graph LM)
 
     // sizes used by the last batch
@@ -209,7 +212,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->pending) (void)hipStreamSynchronize(d->p_stream);  // a batch still in flight reads and writes the workspace
-    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->dense_seg.release(); d->wmask.release(); d->bmask.release();
+    d->rootmask.release(); d->quad_list.release(); d->dense_tiles.release(); d->dense_seg.release(); d->seg_edges.release(); d->wmask.release(); d->bmask.release();
     d->dbg_thresh.release(); d->dbg_labels.release();
     d->frame_ndets.release(); d->frame_idx.release(); d->frame_nkeep.release(); d->frame_off.release(); d->out_det.release(); d->out_pose.release();
     if (d->host_pose) (void)hipHostFree(d->host_pose);
@@ -220,6 +223,9 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->aux_stream) (void)hipStreamDestroy(d->aux_stream);
+    if (d->copy_stream) (void)hipStreamDestroy(d->copy_stream);
+    if (d->host_stream) (void)hipStreamDestroy(d->host_stream);
+    for (hipEvent_t e : d->copy_done) (void)hipEventDestroy(e);
     if (d->d_codes) (void)hipFree(d->d_codes);
     if (d->host_det) (void)hipHostFree(d->host_det);
     if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
@@ -264,14 +270,14 @@ extern "C" int asl_stage_times(asl_detector *d, const char **names, float *ms, i
     return ASL_OK;
 }
 
-// Tags carried per 64-lane wave by the PnP kernels (see k_pnp.inc): few, so that a wave is not held up by the slowest
-// of 64 tags, but not so few that the waves outnumber what the 1024 SIMDs run at once.  `expected` = tags in the launch.
-static int pnp_lpw(size_t expected)
+// Tags per 64-lane wave of the PnP kernels (k_pnp.inc: a quad of lanes per tag, so at most 16): fewer when the launch
+// cannot fill the chip anyway, so that a wave is not held up by the slowest of 16 tags.  `expected` = tags in the launch.
+static int pnp_tpw(size_t expected)
 {
-    const char *e = getenv("ASL_PNP_LPW");  // tuning override
-    if (e) { int x = atoi(e); return x < 1 ? 1 : (x > 64 ? 64 : x); }
-    int v = 8;
-    while (v < 64 && (size_t)v * 640 < expected) v <<= 1;
+    const char *e = getenv("ASL_PNP_TPW");  // tuning override
+    if (e) { int x = atoi(e); return x < 1 ? 1 : (x > 16 ? 16 : x); }
+    int v = 1;  // about a wave per SIMD (1024 of them) before the waves fill up: 20 K tags ran 0.153 / 0.193 / 0.256 ms at 16 / 8 / 4 tags per wave
+    while (v < 16 && (size_t)v * 2 * 1024 <= expected) v <<= 1;
     return v;
 }
 
@@ -336,6 +342,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->frame_cursor.ensure(B);
     bad |= d->dense_tiles.ensure(B * count_tiles(g));
     bad |= d->dense_seg.ensure(B * (size_t)seg_nwx(g) * (size_t)((g.sh + SEG_TH - 1) / SEG_TH));
+    bad |= d->seg_edges.ensure(B * (size_t)seg_nwx(g) * (size_t)((g.sh + SEG_TH - 1) / SEG_TH));
     bad |= d->scratch.ensure((size_t)d->max_points * 8);
     bad |= d->dets.ensure(d->max_dets);
     bad |= d->frame_ndets.ensure(B);
@@ -391,8 +398,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     STAGE("k_seg_tile");
     {
         const int ntiles = nwx * ((g.sh + SEG_TH - 1) / SEG_TH);
-        hipLaunchKernelGGL(k_seg_tile, dim3(ntiles, 1, B), dim3(64), 0, st, d->dgray.p, d->tcut.p, g, nwx,
-                           d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->dense_seg.p, d->counters.p);
+        hipLaunchKernelGGL(k_seg_tile, dim3((ntiles + SEG_TILE_WAVES - 1) / SEG_TILE_WAVES, 1, B), dim3(64 * SEG_TILE_WAVES), 0, st, d->dgray.p, d->tcut.p, g, nwx, ntiles,
+                           d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p, d->rootmask.p, d->seg_edges.p, d->dense_seg.p, d->counters.p);
         // tiles with more runs or links than the common launch's tables hold (none in ordinary frames: the launch finds an empty list)
         hipLaunchKernelGGL(k_seg_tile_dense, dim3(1024), dim3(64), 0, st, g, nwx, ntiles, d->wmask.p, d->bmask.p, d->parent.p, d->sizes.p,
                            d->rootmask.p, d->dense_seg.p, d->counters.p);
@@ -404,8 +411,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
         const int nrb = (g.sh - 1) / SEG_TH;
         const unsigned int nrow_blocks = (unsigned int)nwx * (unsigned int)nrb * (unsigned int)B;
         if (ncol_blocks + nrow_blocks > 0)
-            hipLaunchKernelGGL(k_seg_border, dim3(ncol_blocks + nrow_blocks), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx, d->parent.p, d->counters.p,
-                               ncol_blocks, nrb > 0 ? nrb : 1);
+            hipLaunchKernelGGL(k_seg_border, dim3(ncol_blocks + nrow_blocks), dim3(64), 0, st, d->wmask.p, d->bmask.p, d->seg_edges.p,
+                               nwx * ((g.sh + SEG_TH - 1) / SEG_TH), g, nwx, d->parent.p, d->counters.p, ncol_blocks, nrb > 0 ? nrb : 1);
     }
     STAGE("k_seg_roots");
     hipLaunchKernelGGL(k_seg_roots, dim3((unsigned int)((nwords + 255) / 256)), dim3(256), 0, st, d->rootmask.p, g, nwx, d->parent.p, d->sizes.p);
@@ -473,8 +480,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     range_push("S9 PnP, S8 de-duplication");
     if (cam) {
         STAGE("k_pnp_dets");
-        const int lpw = pnp_lpw(d->nd_guess ? d->nd_guess : (size_t)20 * B);  // detections of the previous batch, else a guess
-        hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + lpw - 1) / lpw), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam, lpw);
+        const int tpw = pnp_tpw(d->nd_guess ? d->nd_guess : (size_t)20 * B);  // detections of the previous batch, else a guess
+        hipLaunchKernelGGL(k_pnp_dets, dim3((d->max_dets + tpw - 1) / tpw), dim3(64), 0, st, d->dets.p, d->counters.p, d->max_dets, *cam, tpw);
     }
     // ---- S8: de-duplicate, order by id, lay out the results
     STAGE("k_det_dedup");
@@ -680,23 +687,74 @@ extern "C" int asl_detect_batch_device(asl_detector *d, const void *d_frames, in
     return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
 }
 
+// Frames that start in host memory (the reference's callers hand over numpy frames: simulation_engine.py:219,
+// video_detection.py:247-258).  All copies are issued up front on a copy stream, one event per chunk of frames; the
+// detector works through the chunks on its own stream, each as soon as its frames have landed, so chunk i's kernels run
+// under chunk i+1's transfer and the call takes the time of the transfer plus one chunk's kernels (the PCIe link is the
+// bound: 2.76 MB per 720p frame against 3.5 us of kernels).  Results are appended chunk by chunk with the frame index
+// of the whole call.  A call of fewer than two chunks is one batch, as before.
+#define HOST_CHUNK_FRAMES 64
+static int detect_host_frames(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
+                              const CamDev *cam, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
+{
+    Geom g;
+    const size_t pitch = (size_t)stride * (size_t)h;
+    int rc = make_geom(d, n_frames, channels, w, h, stride, pitch, &g);
+    if (rc) return rc;
+    if (d->in.ensure(pitch * (size_t)n_frames)) return fail(ASL_ENOMEM, "input staging allocation failed");
+    for (int i = 0; i < n_frames; i++)
+        if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
+    int chunk = HOST_CHUNK_FRAMES;
+    { const char *e = getenv("ASL_HOST_CHUNK"); if (e && atoi(e) > 0) chunk = atoi(e); }  // tuning override
+    const int nchunks = n_frames >= 2 * chunk ? (n_frames + chunk - 1) / chunk : 1;
+    if (nchunks == 1) {
+        for (int i = 0; i < n_frames; i++) HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
+        int rcs = submit_batch(d, d->in.p, g, nullptr, cam);
+        if (rcs) return rcs;
+        return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
+    }
+    if (!d->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking));
+    }
+    while ((int)d->copy_done.size() < nchunks) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->copy_done.push_back(e);
+    }
+    HIPCHK(hipStreamSynchronize(nullptr));  // earlier work of this detector on the null stream may still read d->in
+    for (int c = 0; c < nchunks; c++) {
+        const int f0 = c * chunk, f1 = std::min(n_frames, f0 + chunk);
+        for (int i = f0; i < f1; i++) HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, d->copy_stream));
+        HIPCHK(hipEventRecord(d->copy_done[c], d->copy_stream));
+    }
+    int total = 0;
+    for (int c = 0; c < nchunks; c++) {
+        const int f0 = c * chunk, f1 = std::min(n_frames, f0 + chunk);
+        Geom gc = g;
+        gc.nframes = f1 - f0;
+        HIPCHK(hipStreamWaitEvent(d->host_stream, d->copy_done[c], 0));
+        int rcs = submit_batch(d, d->in.p + (size_t)f0 * pitch, gc, d->host_stream, cam);
+        if (rcs) { (void)hipStreamSynchronize(d->copy_stream); return rcs; }
+        int nc = 0;
+        const int room = std::max(0, max_out - total);
+        rcs = collect_batch(d, out ? out + std::min(total, max_out) : nullptr, (poses && cam) ? poses + std::min(total, max_out) : nullptr, room,
+                            n_per_frame ? n_per_frame + f0 : nullptr, &nc);
+        if (rcs) { (void)hipStreamSynchronize(d->copy_stream); return rcs; }
+        for (int k = total; k < std::min(total + nc, max_out); k++) out[k].frame += f0;  // frame index inside the whole call
+        total += nc;
+    }
+    if (n_out) *n_out = total;
+    return ASL_OK;
+}
+
 extern "C" int asl_detect_batch_u8(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
                                    asl_detection *out, int max_out, int *n_per_frame, int *n_out)
 {
     if (!d || !frames) return fail(ASL_EINVAL, "NULL detector or frames");
+    if (max_out < 0 || (max_out > 0 && !out)) return fail(ASL_EINVAL, "out is NULL");
     HIPCHK(hipSetDevice(d->device));
-    Geom g;
-    size_t pitch = (size_t)stride * (size_t)h;
-    int rc = make_geom(d, n_frames, channels, w, h, stride, pitch, &g);
-    if (rc) return rc;
-    if (d->in.ensure(pitch * (size_t)n_frames)) return fail(ASL_ENOMEM, "input staging allocation failed");
-    for (int i = 0; i < n_frames; i++) {
-        if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
-        HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
-    }
-    int rcs = submit_batch(d, d->in.p, g, nullptr, nullptr);
-    if (rcs) return rcs;
-    return collect_batch(d, out, nullptr, max_out, n_per_frame, n_out);
+    return detect_host_frames(d, frames, n_frames, channels, w, h, stride, nullptr, out, nullptr, max_out, n_per_frame, n_out);
 }
 
 extern "C" int asl_detect_batch_pose_u8(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
@@ -704,22 +762,12 @@ extern "C" int asl_detect_batch_pose_u8(asl_detector *d, const uint8_t *const *f
                                         int max_out, int *n_per_frame, int *n_out)
 {
     if (!d || !frames || !K || !poses) return fail(ASL_EINVAL, "NULL detector, frames, K or poses");
+    if (max_out < 0 || (max_out > 0 && !out)) return fail(ASL_EINVAL, "out is NULL");
     if (n_dist != 0 && n_dist != 4 && n_dist != 5) return fail(ASL_EINVAL, "n_dist must be 0, 4 or 5");
     if (n_dist && !dist) return fail(ASL_EINVAL, "dist is NULL but n_dist = %d", n_dist);
     HIPCHK(hipSetDevice(d->device));
-    Geom g;
-    size_t pitch = (size_t)stride * (size_t)h;
-    int rc = make_geom(d, n_frames, channels, w, h, stride, pitch, &g);
-    if (rc) return rc;
-    if (d->in.ensure(pitch * (size_t)n_frames)) return fail(ASL_ENOMEM, "input staging allocation failed");
-    for (int i = 0; i < n_frames; i++) {
-        if (!frames[i]) return fail(ASL_EINVAL, "frames[%d] is NULL", i);
-        HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
-    }
     CamDev cam = make_cam(d, K, dist, n_dist, tag_size);
-    int rcs = submit_batch(d, d->in.p, g, nullptr, &cam);
-    if (rcs) return rcs;
-    return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
+    return detect_host_frames(d, frames, n_frames, channels, w, h, stride, &cam, out, poses, max_out, n_per_frame, n_out);
 }
 
 extern "C" int asl_detect_gray_u8(asl_detector *d, const uint8_t *gray, int w, int h, int stride, asl_detection *out, int max_out, int *n_out)
@@ -820,7 +868,7 @@ extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const 
     CamDev cam = make_cam(d, K, dist, n_dist, tag_size);
     HIPCHK(hipMemcpy(d->pnp_corners.p, corners, sizeof(float) * 8 * (size_t)N, hipMemcpyHostToDevice));
     double *dr = d->pnp_out.p, *dt = dr + 3 * (size_t)N, *dT = dt + 3 * (size_t)N;
-    hipLaunchKernelGGL(k_pnp_batch, dim3((N + pnp_lpw((size_t)N) - 1) / pnp_lpw((size_t)N)), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p, pnp_lpw((size_t)N));
+    hipLaunchKernelGGL(k_pnp_batch, dim3((N + pnp_tpw((size_t)N) - 1) / pnp_tpw((size_t)N)), dim3(64), 0, nullptr, d->pnp_corners.p, N, cam, dr, dt, dT, d->pnp_ok.p, pnp_tpw((size_t)N));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(rvec, dr, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tvec, dt, sizeof(double) * 3 * (size_t)N, hipMemcpyDeviceToHost));

@@ -303,9 +303,10 @@ def cpu_baseline_all_cores(frames, K, budget_s=10.0):
             "sample": "%d frames in %.1f s wall (%d processes x %.0f s of the same %dx%dx%d-tag stream, oracle/ detect_bgr + solve_pnp built %s)" % (total, wall, cores, budget_s, W, H, NTAGS, CPU_FLAGS)}
 
 
-def h2d_included(det, d_frames, K, n=256, reps=3):
-    """frames/s when the frames start in (page-locked) HOST memory: asl_detect_batch_pose_u8 copies them over PCIe, then
-    runs the same batch.  Reported next to `value`, never as `value`."""
+def h2d_included(det, d_frames, K, n=512, reps=3):
+    """frames/s when the frames start in (page-locked) HOST memory: asl_detect_batch_pose_u8 copies them over PCIe in chunks
+    and runs each chunk's kernels under the next chunk's transfer.  Reported next to `value`, never as `value`.  The bare
+    transfer of the same bytes is timed beside it: the link is the bound, `frac_of_link` says how close the call comes."""
     import torch
     n = min(n, d_frames.shape[0])
     host = d_frames[:n].cpu().pin_memory()
@@ -316,9 +317,41 @@ def h2d_included(det, d_frames, K, n=256, reps=3):
     for _ in range(reps):
         det.detect_host(a, K=K, dist=np.zeros(4), tag_size=TAG_INNER)
     dt = (time.perf_counter() - t0) / reps
+    dst = torch.empty_like(d_frames[:n])
+    dst.copy_(host, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dst.copy_(host, non_blocking=True)
+    torch.cuda.synchronize()
+    dt_copy = (time.perf_counter() - t0) / reps
+    nbytes = n * W * H * 3
     return {"value": n / dt, "unit": "frames/s", "frames_per_call": n, "ms_per_call": 1e3 * dt,
-            "host_to_device_GBs": n * W * H * 3 / dt / 1e9,
-            "note": "asl_detect_batch_pose_u8 from page-locked host frames: PCIe copy + the same batch, synchronous"}
+            "host_to_device_GBs": nbytes / dt / 1e9, "link_GBs": nbytes / dt_copy / 1e9, "link_limited_frames_per_s": n / dt_copy,
+            "frac_of_link": dt_copy / dt,
+            "note": "asl_detect_batch_pose_u8 from page-locked host frames: PCIe copy in chunks of 64 frames, each chunk's kernels under the next chunk's transfer; link_GBs = one plain pinned-to-device copy of the same bytes"}
+
+
+def stage_at_decimate_1(d_frames, K, nframes=256):
+    """SURVEY.md 8(d) asks for the threshold + segmentation stage at decimate = 1 as well (R = 6 W H, + 2 W H for BGR in the
+    timed region): one synchronous batch on a detector built with decimate = 1 (parity-tested: tests/test_gpu_parity.py)."""
+    from aprilslam_amd import _lib
+    n = min(nframes, d_frames.shape[0])
+    det = _lib.Detector("tagStandard41h12", decimate=1.0, id_limit=0)
+    try:
+        det.set_profiling(True)
+        for _ in range(2):  # the first call allocates the workspace
+            det.submit_device(d_frames.data_ptr(), n, 3, W, H, stream=0, K=K, dist=np.zeros(4), tag_size=TAG_INNER)
+            det.collect(max_per_frame=MAXDET)
+        t = det.stage_times()
+    finally:
+        det.close()
+    names = ("k_hash_clear", "k_decimate_minmax", "k_tile_cut", "k_seg_tile", "k_seg_border", "k_seg_roots", "k_seg_points", "k_cluster_filter", "k_point_place")
+    ms = sum(t.get(k, 0.0) for k in names)
+    rb = stage_algorithmic_read_bytes(W, H, 3, 1)
+    gbs = rb * n / (ms * 1e-3) / 1e9
+    return {"decimate": 1, "frames": n, "ms_per_batch_isolated": ms, "algorithmic_read_bytes_per_frame": rb, "achieved_GBs": gbs,
+            "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "members_ms": {k: t.get(k, 0.0) for k in names}}
 
 
 def project_serial_term(det, d_frames, K, dev, max_tags, world=8, reps=5):
@@ -735,6 +768,8 @@ def main():
             line["pose_rmse_both_minima"]["k_pnp_dets_ms"] = detectors[0].stage_times().get("k_pnp_dets")
             line["h2d_included"] = h2d_included(detectors[0], d_frames, K)
             line["multi_gpu_projection"] = project_serial_term(detectors[0], d_frames, K, dev, MT)
+            if args.workload == "configs1":
+                line["stage_threshold_segmentation_decimate1"] = stage_at_decimate_1(d_frames, K)
             if ndist == B:
                 # the producer inside the step: every step first renders its B frames on the device, then detects
                 def rstep(k_):

@@ -213,3 +213,31 @@ def test_device_last_sightings_of_a_stretch(family):
                 assert p_dev[2 * t].tobytes() == p_ref[2 * t].tobytes() and p_dev[2 * t + 1].tobytes() == p_ref[2 * t + 1].tobytes()
     finally:
         det.close()
+
+
+def test_host_batch_in_chunks_equals_the_device_batch(family):
+    """Frames handed over in host memory (asl_detect_batch_pose_u8 / asl_detect_batch_u8) are copied and processed in chunks
+    of 64 so that the transfer of one chunk hides the kernels of the one before; the results, appended chunk by chunk,
+    must be those of one batch over the same frames resident on the device: same order, same frame indices, same bits."""
+    import torch
+    w, h, nd = 320, 240, 12
+    distinct = np.stack([_scene(w, h, 2 + s % 4, 9000 + s, noise=float(s % 2)) for s in range(nd)])
+    n = 150  # three chunks, the last one ragged
+    frames = np.ascontiguousarray(distinct[np.arange(n) % nd])
+    frames[37] = 128  # a frame without detections in the middle of a chunk
+    K = synth.camera_matrix(w, h)
+    det = _lib.Detector("tagStandard41h12", id_limit=0)
+    try:
+        d_frames = torch.from_numpy(frames).to("cuda:0")
+        rd, rp, rn = det.detect_device(d_frames.data_ptr(), n, 3, w, h, K=K, dist=np.zeros(4), tag_size=10.0)
+        rd, rp, rn = rd.copy(), rp.copy(), rn.copy()
+        hd, hp, hn = det.detect_host(frames, K=K, dist=np.zeros(4), tag_size=10.0)
+        assert np.array_equal(hn, rn) and len(hd) == len(rd) > 2 * n
+        assert hd.tobytes() == rd.tobytes() and hp.tobytes() == rp.tobytes()
+        assert np.array_equal(hd["frame"], np.repeat(np.arange(n), rn))
+        gd, gn = det.detect_host(frames)  # without poses: asl_detect_batch_u8, same chunks
+        assert np.array_equal(gn, rn) and gd.tobytes() == rd.tobytes()
+        small, sp, sn = det.detect_host(frames[:100], K=K, dist=np.zeros(4), tag_size=10.0)  # fewer than two chunks: one batch
+        assert small.tobytes() == rd[:len(small)].tobytes() and np.array_equal(sn, rn[:100])
+    finally:
+        det.close()
