@@ -694,6 +694,21 @@ extern "C" int asl_detect_batch_device(asl_detector *d, const void *d_frames, in
 // bound: 2.76 MB per 720p frame against 3.5 us of kernels).  Results are appended chunk by chunk with the frame index
 // of the whole call.  A call of fewer than two chunks is one batch, as before.
 #define HOST_CHUNK_FRAMES 64
+// frames [f0, f1) into the staging buffer; frames that follow each other in host memory (one array, the usual case) go as
+// one transfer (a call per 2.76 MB frame costs ~12 us: 6 ms on 512 frames against 25 ms of transfer)
+static hipError_t copy_frames(asl_detector *d, const uint8_t *const *frames, int f0, int f1, size_t pitch, hipStream_t st)
+{
+    int i = f0;
+    while (i < f1) {
+        int j = i + 1;
+        while (j < f1 && frames[j] == frames[j - 1] + pitch) j++;
+        hipError_t e = hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch * (size_t)(j - i), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        i = j;
+    }
+    return hipSuccess;
+}
+
 static int detect_host_frames(asl_detector *d, const uint8_t *const *frames, int n_frames, int channels, int w, int h, int stride,
                               const CamDev *cam, asl_detection *out, asl_pose *poses, int max_out, int *n_per_frame, int *n_out)
 {
@@ -708,7 +723,7 @@ static int detect_host_frames(asl_detector *d, const uint8_t *const *frames, int
     { const char *e = getenv("ASL_HOST_CHUNK"); if (e && atoi(e) > 0) chunk = atoi(e); }  // tuning override
     const int nchunks = n_frames >= 2 * chunk ? (n_frames + chunk - 1) / chunk : 1;
     if (nchunks == 1) {
-        for (int i = 0; i < n_frames; i++) HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, nullptr));
+        HIPCHK(copy_frames(d, frames, 0, n_frames, pitch, nullptr));
         int rcs = submit_batch(d, d->in.p, g, nullptr, cam);
         if (rcs) return rcs;
         return collect_batch(d, out, poses, max_out, n_per_frame, n_out);
@@ -725,7 +740,7 @@ static int detect_host_frames(asl_detector *d, const uint8_t *const *frames, int
     HIPCHK(hipStreamSynchronize(nullptr));  // earlier work of this detector on the null stream may still read d->in
     for (int c = 0; c < nchunks; c++) {
         const int f0 = c * chunk, f1 = std::min(n_frames, f0 + chunk);
-        for (int i = f0; i < f1; i++) HIPCHK(hipMemcpyAsync(d->in.p + (size_t)i * pitch, frames[i], pitch, hipMemcpyHostToDevice, d->copy_stream));
+        HIPCHK(copy_frames(d, frames, f0, f1, pitch, d->copy_stream));
         HIPCHK(hipEventRecord(d->copy_done[c], d->copy_stream));
     }
     int total = 0;

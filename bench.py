@@ -440,6 +440,7 @@ def main():
         args.max_tags = NTAGS + 4
     if args.gn_every < 0:
         args.gn_every = wl["gn_every"]
+    args.gn_frames = max(1, min(args.gn_frames, args.batch - 1))  # the LM window and the frame before it come out of one block
     global MAXDET
     MAXDET = max(64, 2 * NTAGS)
     args.exchange = args.exchange or wl["exchange"]

@@ -253,6 +253,23 @@ def test_gn_backend_matches_cpu_restatement(gpu_detector):
             assert np.abs(tag_g - pr["tag_gt"]).max() < 1e-6 and np.abs(cam_g - pr["cam_gt"]).max() < 1e-6
 
 
+def test_gn_backend_full_size_system(gpu_detector):
+    """The system of BASELINE.json configs[4]: 24 cameras x 200 tags of a 3840 x 2160 view, ~3,800 observations, a
+    1,200 x 1,200 reduced system = 25 block columns of the blocked Cholesky (the shape profiles/r0*_gn_kernel_stats.csv
+    profiles).  Same damping schedule on both sides, so the iterates agree to rounding."""
+    from gn_problem import G, make_problem
+    pr = make_problem(P=24, L=200, seed=6, noise=0.25, width=3840, height=2160)
+    assert len(pr["obs_cam"]) > 3000
+    args = (pr["cam0"], pr["tag0"], pr["obs_cam"], pr["obs_tag"], pr["obs_corners"], pr["K"], 10.0, 0)
+    cam_o, tag_o, st_o = G.solve(*args, iters=6)
+    cam_g, tag_g, st_g = gpu_detector.gn_solve(*args, iters=6)
+    assert min(st_g[2], st_o[2]) >= 3, (st_g, st_o)
+    assert abs(st_g[0] - st_o[0]) <= 1e-9 * st_o[0]
+    assert abs(st_g[1] - st_o[1]) <= 1e-6 * st_o[1]
+    assert st_g[1] / len(pr["obs_cam"]) < 1.0  # 8 residuals of 0.25 px noise per observation: 0.5 px^2
+    assert np.abs(tag_g - tag_o).max() < 1e-6 and np.abs(cam_g - cam_o).max() < 1e-6
+
+
 @pytest.mark.parametrize("w,h,ntags,seed", [(1920, 1080, 50, 21), (3840, 2160, 200, 22)])
 def test_large_config_stage_parity(gpu_detector, family, w, h, ntags, seed):
     """BASELINE.json configs[2] (1080p, 50 tags) and configs[4] (2160p, 200 tags) as single-frame parity cases:
