@@ -15,7 +15,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" \
   name=$1; shift
   case " $want " in *" $name "*) ;; *) continue ;; esac
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline > $R/gpurun_out/pmc_${tag}_$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python3 $R/bench.py --steps 2 --warmup 1 --pipeline 1 --timed-only > $R/gpurun_out/pmc_${tag}_$name.log 2>&1
   python3 $R/tools/pmc_summary.py /tmp/pmc_$name $R/gpurun_out/pmc_${tag}_$name.csv
   echo "pass $name done"
 done

@@ -10,7 +10,7 @@ python bench.py > $O/${tag}_bench_final.log 2> $O/${tag}_bench_final.err
 echo "bench done: $(tail -c 300 $O/${tag}_bench_final.log | head -c 120)"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_f
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -- python3 $R/bench.py --no-cpu-baseline > $O/${tag}_prof_f.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -- python3 $R/bench.py --timed-only > $O/${tag}_prof_f.log 2>&1
 cp $(ls /tmp/prof_f/*/*kernel_stats.csv | head -1) $O/${tag}_f_kernel_stats.csv
 echo "kernel trace done"
 bash $R/tools/pmc_run.sh $tag
