@@ -698,7 +698,8 @@ def main():
         # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc pass of the same build
         tr = None
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            import glob
+            tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_traffic.json")))[-1]))  # the latest round's counter passes
             if tr.get("batch_frames") != B:
                 tr = None
         except Exception:
