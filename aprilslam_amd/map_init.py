@@ -32,12 +32,13 @@ def reprojection_cost(cam_from_tag, corners, K, tag_size):
     """Sum of squared pixel errors of (..., 4, 4) camera<-tag poses against (..., 4, 2) corners; points behind the
     camera cost a large constant."""
     X = _corners_obj(tag_size)
-    p = np.einsum('...ij,kj->...ki', cam_from_tag[..., :3, :], X)
-    z = p[..., 2]
+    # the corners lie in the tag's plane (z = 0): p = R[:, :2] (x, y) + t, as one small matrix product per pose
+    p = cam_from_tag[..., :3, :2] @ X[:, :2].T + cam_from_tag[..., :3, 3:4]          # (..., 3, 4 corners)
+    z = p[..., 2, :]
     ok = z > 1e-9
     zs = np.where(ok, z, 1.0)
-    u = K[0, 0] * p[..., 0] / zs + K[0, 2]
-    v = K[1, 1] * p[..., 1] / zs + K[1, 2]
+    u = K[0, 0] * p[..., 0, :] / zs + K[0, 2]
+    v = K[1, 1] * p[..., 1, :] / zs + K[1, 2]
     e = (u - corners[..., 0]) ** 2 + (v - corners[..., 1]) ** 2
     return np.where(ok, e, 1e12).sum(axis=-1)
 
