@@ -844,8 +844,9 @@ extern "C" int asl_graph_frames_device(asl_detector *d, const void *d_obs, int w
     if (world <= 0 || n_frames <= 0 || max_tags <= 0 || n_ids <= 0) return fail(ASL_EINVAL, "sizes must be positive");
     HIPCHK(hipSetDevice(d->device));
     const unsigned int total = (unsigned int)world * (unsigned int)n_frames;
-    hipLaunchKernelGGL(k_graph_frames, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
-                       coordinate_id, d_pose, d_status, (unsigned int *)d_last, n_ids);
+    const int lds_ids = (size_t)n_ids * sizeof(unsigned int) <= 48 * 1024 ? n_ids : 0;  // the table as an LDS copy per workgroup, if it fits
+    hipLaunchKernelGGL(k_graph_frames, dim3((total + 255) / 256), dim3(256), sizeof(unsigned int) * (size_t)lds_ids, (hipStream_t)stream, (const ObsRec *)d_obs,
+                       world, n_frames, max_tags, coordinate_id, d_pose, d_status, (unsigned int *)d_last, n_ids, lds_ids);
     if (d_picks)
         hipLaunchKernelGGL(k_graph_pick, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
                            (const unsigned int *)d_last, n_ids, (ObsRec *)d_picks);
@@ -862,8 +863,9 @@ extern "C" int asl_graph_picks_device(asl_detector *d, const void *d_obs, int wo
     HIPCHK(hipSetDevice(d->device));
     HIPCHK(hipMemsetAsync(d_last, 0, sizeof(uint32_t) * (size_t)n_ids, (hipStream_t)stream));
     const unsigned int total = (unsigned int)world * (unsigned int)n_frames;
-    hipLaunchKernelGGL(k_graph_last_range, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
-                       d_status, order_lo, order_hi, (unsigned int *)d_last, n_ids);
+    const int lds_ids = (size_t)n_ids * sizeof(unsigned int) <= 48 * 1024 ? n_ids : 0;
+    hipLaunchKernelGGL(k_graph_last_range, dim3((total + 255) / 256), dim3(256), sizeof(unsigned int) * (size_t)lds_ids, (hipStream_t)stream, (const ObsRec *)d_obs,
+                       world, n_frames, max_tags, d_status, order_lo, order_hi, (unsigned int *)d_last, n_ids, lds_ids);
     hipLaunchKernelGGL(k_graph_pick, dim3((n_ids + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const ObsRec *)d_obs, world, n_frames, max_tags,
                        (const unsigned int *)d_last, n_ids, (ObsRec *)d_picks);
     HIPCHK(hipGetLastError());
