@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,count,seed", [("fuzz_parity.py", 40, 2025), ("fuzz_clutter.py", 40, 2025)])
+@pytest.mark.parametrize("tool,count,seed", [("fuzz_parity.py", 300, 2025), ("fuzz_clutter.py", 300, 2025)])
 def test_randomised_sweep(tool, count, seed):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(count), str(seed)], cwd=ROOT, capture_output=True, timeout=900)
     out = p.stdout.decode(errors="replace")
