@@ -90,28 +90,27 @@ struct CamDev {
     int pad;
 };
 
-// counters living in device memory (zeroed per batch)
+// counters living in device memory (zeroed per batch).  The ones that whole launches add to sit 128 bytes apart: atomics on
+// one cache line are served one at a time (~10 ns each, measured in k_graph_frames), and k_cluster_filter's seven block
+// totals per workgroup used to share two lines -- most of that kernel's time.
 enum {
     CNT_NCLUSTERS = 0,  // surviving clusters
-    CNT_NPOINTS,        // points reserved for surviving clusters
-    CNT_NDETS,          // detections appended
-    CNT_OVERFLOW_HASH,
-    CNT_OVERFLOW_POINTS,
-    CNT_OVERFLOW_CLUSTERS,
-    CNT_OVERFLOW_DETS,
-    CNT_NQUADS,
-    CNT_CLASS0,  // clusters per size class (lists consumed by the fit kernels)
-    CNT_CLASS1,
-    CNT_CLASS2,
-    CNT_CLASS3,
-    CNT_CLASS4,
-    CNT_DENSE_TILES,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
-    CNT_UF_GUARD,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
-    CNT_NKEEP,        // detections that survive the de-duplication (what the caller receives)
-    CNT_DEDUP_LIMIT,  // frames with more detections than the de-duplication sorts (fails the batch loudly)
-    CNT_DENSE_SEG,    // tiles of the labelling pass with more runs or links than its LDS tables hold (k_seg_tile_dense takes them)
-    CNT__N = 24
+    CNT_OVERFLOW_HASH = 1,
+    CNT_OVERFLOW_POINTS = 2,
+    CNT_OVERFLOW_CLUSTERS = 3,
+    CNT_OVERFLOW_DETS = 4,
+    CNT_UF_GUARD = 5,     // a union-find loop ran into its iteration guard (never seen; fails the batch loudly)
+    CNT_DEDUP_LIMIT = 6,  // frames with more detections than the de-duplication sorts (fails the batch loudly)
+    CNT_NPOINTS = 16,     // points reserved for surviving clusters
+    CNT_CLASS0 = 32,      // clusters per size class (lists consumed by the fit kernels): CNT_CLASS(c)
+    CNT_NDETS = 112,      // detections appended
+    CNT_NQUADS = 128,
+    CNT_NKEEP = 144,      // detections that survive the de-duplication (what the caller receives)
+    CNT_DENSE_TILES = 160,  // tiles of the cluster pass with more points than a workgroup parks in its small LDS buffer
+    CNT_DENSE_SEG = 161,    // tiles of the labelling pass with more runs or links than its LDS tables hold (k_seg_tile_dense takes them)
+    CNT__N = 176
 };
+#define CNT_CLASS(c) (CNT_CLASS0 + 16 * (c))
 
 // A batch whose work buffers overflowed is re-run by the host after growing them; until then its cluster
 // lists and quad records have holes, so every consumer kernel backs out first thing.
