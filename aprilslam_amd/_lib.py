@@ -360,6 +360,21 @@ class Detector:
         check(self._L.asl_debug_fetch(self._h, 4, buf.ctypes.data, buf.nbytes, C.byref(n)))
         return buf[:n.value]
 
+    def debug_clusters(self):
+        """(n, 3) uint64: key, point count, hash of the sorted point records of every cluster of the last batch, by key."""
+        ncl = int(self.debug_counters()[3])
+        buf = np.zeros((max(ncl, 1), 3), dtype=np.uint64)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, 6, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        return buf[:n.value]
+
+    def debug_refit(self, reps):
+        """Re-run the quad fit of the last batch `reps` times; int64[7]: reps, quads differing from the first run, by size class."""
+        buf = np.zeros(7, dtype=np.int64)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, 7, buf.ctypes.data, int(reps), C.byref(n)))
+        return buf
+
     def phase_cycles(self, reset=True):
         buf = (C.c_uint64 * 64)()
         check(self._L.asl_debug_phase_cycles(self._h, buf, 1 if reset else 0))

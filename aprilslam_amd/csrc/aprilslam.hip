@@ -366,6 +366,40 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     } while (0)
 
 // enqueue the whole detector for frames resident at d_frames; no host sync
+// Quad fit of one size class (k_quad.inc): grid-stride kernels over the class's device-side cluster list -- many more
+// workgroups than fit on the chip, so the heavy-tailed per-cluster costs balance out (workgroups without work leave at once).
+static void launch_fit_class(asl_detector *d, const Geom &g, int cls, unsigned int B, hipStream_t st)
+{
+    const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
+    int tag_width = d->fam.width_at_border / g.f;
+    if (tag_width < 3) tag_width = 3;
+    const unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
+    const unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
+    const unsigned int *list = d->class_lists.p + (size_t)cls * d->max_clusters;
+    switch (cls) {
+    case 0:
+        hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, list, d->counters.p, 0,
+                           d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+        break;
+    case 1:  // two wavefronts per cluster: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
+        hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), QUAD_LDS_BYTES(CLASS1_CAP), st, d->clusters.p, list, d->counters.p, 1,
+                           d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+        break;
+    case 2:
+        hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS2_CAP), st, d->clusters.p, list, d->counters.p, 2,
+                           d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+        break;
+    case 3:
+        hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS3_CAP), st, d->clusters.p, list, d->counters.p, 3,
+                           d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+        break;
+    default:
+        hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(q2grid), dim3(256), 0, st, d->clusters.p, list, d->counters.p, 4, d->max_clusters, 0, d->points.p,
+                           d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+        break;
+    }
+}
+
 static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
 {
     dim3 blk(64, 4, 1);
@@ -425,8 +459,6 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     hipLaunchKernelGGL((k_seg_points<SEGP_PCAP_DENSE, SEGP_RUNCAP_DENSE, 1, 2>), dim3(256), dim3(64), 0, st, d->wmask.p, d->bmask.p, g, nwx,
                        d->parent.p, d->sizes.p, d->hkeys.p, d->hcounts.p, d->nslots - 1, d->stage_rec.p, d->stage_pos.p, d->frame_cursor.p,
                        d->stage_cap, d->dense_tiles.p, pty, d->counters.p);
-    int tag_width = d->fam.width_at_border / g.f;
-    if (tag_width < 3) tag_width = 3;
     STAGE("k_cluster_filter");
     hipLaunchKernelGGL(k_cluster_filter, dim3((d->nslots + 1023) / 1024), dim3(1024), 0, st, d->hkeys.p, d->hcounts.p, d->nslots, g,
                        d->clusters.p, d->slot_cluster.p, d->class_lists.p, d->max_clusters, d->max_points, d->counters.p);
@@ -435,33 +467,13 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
                        d->slot_cluster.p, d->points.p, d->counters.p);
 
     // one launch per size class; each walks its own cluster list (grid-stride)
-    const int want_rev = d->fam.reversed_border ? 1 : 0, want_norm = d->fam.reversed_border ? 0 : 1;
-    // grid-stride kernels over device-side work lists: many more workgroups than fit on the chip, so the heavy-tailed
-    // per-cluster / per-quad costs balance out (workgroups without work leave at once)
-    unsigned int qgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(16384u, 32u * B));
-    unsigned int q2grid = std::min<unsigned int>(d->max_clusters, 2048u);
     range_pop();
     range_push("S5 quad fit");
-    STAGE("k_fit_quads<0>");
-    hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, d->class_lists.p, d->counters.p, 0,
-                       d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
-    STAGE("k_fit_quads<1>");
-    // two wavefronts per cluster here: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
-    hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), QUAD_LDS_BYTES(CLASS1_CAP), st, d->clusters.p,
-                       d->class_lists.p + (size_t)1 * d->max_clusters, d->counters.p, 1, d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
-    STAGE("k_fit_quads<2>");
-    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS2_CAP), st, d->clusters.p,
-                       d->class_lists.p + (size_t)2 * d->max_clusters, d->counters.p, 2, d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
-    STAGE("k_fit_quads<3>");
-    hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS3_CAP), st, d->clusters.p,
-                       d->class_lists.p + (size_t)3 * d->max_clusters, d->counters.p, 3, d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
-    STAGE("k_fit_quads<4>");
-    hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(std::min<unsigned int>(d->max_clusters, 2048u)), dim3(256), 0, st, d->clusters.p,
-                       d->class_lists.p + (size_t)4 * d->max_clusters, d->counters.p, 4, d->max_clusters, 0, d->points.p, d->dgray.p, g,
-                       tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+    for (int cls = 0; cls < NCLASSES; cls++) {
+        static const char *const kFitStage[NCLASSES] = {"k_fit_quads<0>", "k_fit_quads<1>", "k_fit_quads<2>", "k_fit_quads<3>", "k_fit_quads<4>"};
+        STAGE(kFitStage[cls]);
+        launch_fit_class(d, g, cls, B, st);
+    }
 
     range_pop();
     range_push("S6-S7 edge refinement, homography, decode");
@@ -973,6 +985,56 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
         o[13] = d->last_counters[CNT_OVERFLOW_POINTS]; o[14] = d->last_counters[CNT_OVERFLOW_DETS]; o[15] = d->last_counters[CNT_CLASS0];
         o[16] = d->last_counters[CNT_DENSE_TILES]; o[17] = d->last_counters[CNT_DENSE_SEG];  // tiles that took the dense launches
         *n_items = 18;
+        return ASL_OK;
+    }
+    case 6: {  // clusters as the quad fit receives them: (key, count, hash of the sorted point records), ordered by key
+        size_t ncl = (size_t)std::min<long long>(d->last_counters[CNT_NCLUSTERS], (long long)d->max_clusters);
+        size_t npts = (size_t)std::min<long long>(d->last_counters[CNT_NPOINTS], (long long)d->max_points);
+        if (bytes < ncl * 24) return fail(ASL_EINVAL, "dst too small: need %zu bytes", ncl * 24);
+        std::vector<ClusterRec> cl(ncl);
+        std::vector<unsigned long long> pts(npts);
+        if (ncl) HIPCHK(hipMemcpy(cl.data(), d->clusters.p, ncl * sizeof(ClusterRec), hipMemcpyDeviceToHost));
+        if (npts) HIPCHK(hipMemcpy(pts.data(), d->points.p, npts * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::sort(cl.begin(), cl.end(), [](const ClusterRec &a, const ClusterRec &b) { return a.key < b.key; });
+        unsigned long long *o = (unsigned long long *)dst;
+        for (size_t i = 0; i < ncl; i++) {
+            unsigned long long h = 0xcbf29ce484222325ull;
+            if ((size_t)cl[i].offset + cl[i].count <= npts) {
+                std::sort(pts.begin() + cl[i].offset, pts.begin() + cl[i].offset + cl[i].count);
+                for (unsigned int k = 0; k < cl[i].count; k++) { h ^= pts[(size_t)cl[i].offset + k]; h *= 0x100000001b3ull; }
+            }
+            o[3 * i] = cl[i].key; o[3 * i + 1] = cl[i].count; o[3 * i + 2] = h;
+        }
+        *n_items = ncl;
+        return ASL_OK;
+    }
+    case 7: {  // run the quad fit of the last batch again, `bytes` times, on the buffers it left behind: dst (int64[2 + NCLASSES])
+        // receives the repetitions, the quads that came out differently from the first repetition, and those by size class.
+        // The fit is a pure function of the clusters, so any difference is a race.
+        if (d->pending) return fail(ASL_EINVAL, "a batch is in flight on this detector");
+        size_t ncl = (size_t)std::min<long long>(d->last_counters[CNT_NCLUSTERS], (long long)d->max_clusters);
+        if (!ncl) return fail(ASL_EINVAL, "no clusters in the last batch");
+        const size_t reps = bytes;
+        std::vector<QuadRec> ref(ncl), cur(ncl);
+        std::vector<ClusterRec> cl(ncl);
+        HIPCHK(hipMemcpy(cl.data(), d->clusters.p, ncl * sizeof(ClusterRec), hipMemcpyDeviceToHost));
+        long long *o = (long long *)dst;
+        for (int k = 0; k < 2 + NCLASSES; k++) o[k] = 0;
+        for (size_t r = 0; r < reps; r++) {
+            for (int cls = 0; cls < NCLASSES; cls++) launch_fit_class(d, g, cls, (unsigned int)g.nframes, nullptr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy((r ? cur : ref).data(), d->quads.p, ncl * sizeof(QuadRec), hipMemcpyDeviceToHost));
+            if (!r) continue;
+            for (size_t i = 0; i < ncl; i++) {
+                const bool same = cur[i].valid == ref[i].valid && (!ref[i].valid || memcmp(cur[i].p, ref[i].p, sizeof ref[i].p) == 0);
+                if (same) continue;
+                const unsigned int cnt = cl[i].count;
+                o[1]++;
+                o[2 + (cnt <= CLASS0_CAP ? 0 : (cnt <= CLASS1_CAP ? 1 : (cnt <= CLASS2_CAP ? 2 : (cnt <= CLASS3_CAP ? 3 : 4))))]++;
+            }
+        }
+        o[0] = (long long)reps;
+        *n_items = 2 + NCLASSES;
         return ASL_OK;
     }
     default:

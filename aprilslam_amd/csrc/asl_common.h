@@ -112,6 +112,35 @@ enum {
 };
 #define CNT_CLASS(c) (CNT_CLASS0 + 16 * (c))
 
+// IEEE double division with the denominator's part done once.  The compiler expands a / d to v_div_scale x2, v_rcp_f64,
+// two Newton steps on the reciprocal (4 fma), q = a*r, rem = fma(-d, q, a), v_div_fmas (= fma(rem, r, q) unless
+// v_div_scale rescaled an operand), v_div_fixup (passes q through unless an operand or the quotient is zero, subnormal,
+// infinite or NaN): 11 instructions, 6 of which depend on d alone.  Recip keeps those; div_by() is the other three, the
+// same operations on the same values, so the quotient is the correctly rounded one, bit for bit -- PROVIDED neither
+// rescaling nor fix-up would have acted: d normal and finite with |d| in [2^-1000, 2^1000], a zero or of like magnitude,
+// |a/d| in [2^-1000, 2^1000] (v_div_scale acts on exponent differences >= 768 and on operands below 2^-970; a = +0
+// gives +0 either way; a = -0 would give +0 here and -0 there: callers pass sums and differences, where x - x = +0).
+// The moments, covariances and pixel coordinates of the quad path are within 2^+-80.  tools/div_test.hip compares the two
+// forms on the device.
+struct Recip {
+    double d, r;
+};
+__device__ __forceinline__ Recip recip_of(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return Recip{d, r};
+}
+__device__ __forceinline__ double div_by(double a, const Recip &k)
+{
+    const double q = a * k.r;
+    const double rem = __builtin_fma(-k.d, q, a);
+    return __builtin_fma(rem, k.r, q);
+}
+
 // A batch whose work buffers overflowed is re-run by the host after growing them; until then its cluster
 // lists and quad records have holes, so every consumer kernel backs out first thing.
 __device__ __forceinline__ bool batch_poisoned(const long long *counters)

@@ -210,6 +210,9 @@ int asl_render_frames_device(asl_detector *det, void *d_frames, int n_frames, in
          2 = component labels (u32, B*sh*sw)  3 = component sizes by label (u32, B*sh*sw)
          4 = candidate quads (asl_debug_quad, count via *n_items)
          5 = stage counters (int64[18]: frames, sw, sh, clusters, points, quads, detections, ..., tiles of the two dense launches)
+         7 = diagnostic: re-run the quad fit of the last batch `bytes` times on the device buffers it left behind; dst receives
+             int64[7]: repetitions, quads that differ from the first repetition, and those by size class (any is a race)
+         6 = clusters handed to the quad fit (uint64[3] each: key, points, hash of the sorted point records), ordered by key
    bytes = capacity of dst; *n_items = number of elements written. */
 typedef struct {
     double p[4][2]; /* decimated-image pixel coordinates, before the full-resolution rescale */

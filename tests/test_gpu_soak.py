@@ -241,3 +241,27 @@ def test_host_batch_in_chunks_equals_the_device_batch(family):
         assert small.tobytes() == rd[:len(small)].tobytes() and np.array_equal(sn, rn[:100])
     finally:
         det.close()
+
+
+def test_quad_fit_gives_the_same_quads_every_time():
+    """The quad fit is a pure function of the clusters: run again and again on the buffers one batch left behind
+    (asl_debug_fetch item 7) it must return the same quads.  Round 3 found a flag shared by three checks in k_fit_quads
+    that let the two wavefronts of a workgroup fall one barrier apart: one quad lost in ~170 batches of 1024 frames,
+    invisible to every comparison against the oracle (tools/race_hunt.py is the long form of this test)."""
+    import torch
+
+    import bench
+    det = _lib.Detector("tagStandard41h12", decimate=2.0, id_limit=0)
+    try:
+        dev = torch.device("cuda", 0)
+        B = 256
+        d_frames, _, _ = bench.render_stream_device(det, B, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        K = synth.camera_matrix(bench.W, bench.H)
+        det.submit_device(d_frames.data_ptr(), B, 3, bench.W, bench.H, stream=st, K=K, dist=np.zeros(4), tag_size=bench.TAG_INNER)
+        dets, _, _ = det.collect(max_per_frame=bench.MAXDET)
+        assert len(dets) == 20 * B
+        r = det.debug_refit(3000)
+        assert int(r[0]) == 3000 and int(r[1]) == 0, r.tolist()
+    finally:
+        det.close()
