@@ -100,7 +100,7 @@ struct asl_detector {
     DevBuf<unsigned long long> slot_cluster;  // per hash slot: offset | count << 32 of its cluster's segment
     DevBuf<ClusterRec> clusters;
     DevBuf<QuadRec> quads;
-    DevBuf<double> scratch, quadH, wtab;
+    DevBuf<double> scratch, quadH, wtab, side_mom;  // side_mom: 4 x 6 moments per cluster, k_fit_quads -> k_quad_finish
     DevBuf<DetRec> dets;
     // S8 on the device: per-frame index lists, counts and offsets, and the results in the ABI's layout
     DevBuf<unsigned int> frame_ndets, frame_idx, frame_nkeep, frame_off;
@@ -219,7 +219,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->host_nkeep) (void)hipHostFree(d->host_nkeep);
     d->in.release(); d->dgray.release(); d->tmin.release(); d->tmax.release(); d->tcut.release();
     d->parent.release(); d->sizes.release(); d->hkeys.release(); d->points.release(); d->hcounts.release(); d->class_lists.release(); d->stage_pos.release(); d->frame_cursor.release(); d->stage_rec.release();
-    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->quadH.release(); d->wtab.release(); d->dets.release();
+    d->slot_cluster.release(); d->clusters.release(); d->quads.release(); d->scratch.release(); d->side_mom.release(); d->quadH.release(); d->wtab.release(); d->dets.release();
     d->counters.release(); d->pnp_corners.release(); d->pnp_out.release(); d->pnp_ok.release();
     d->gn.release();
     if (d->aux_stream) (void)hipStreamDestroy(d->aux_stream);
@@ -335,6 +335,7 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     bad |= d->quads.ensure(d->max_clusters);
     bad |= d->quad_list.ensure(d->max_clusters);
     bad |= d->quadH.ensure((size_t)10 * d->max_clusters);
+    bad |= d->side_mom.ensure((size_t)24 * d->max_clusters);
     bad |= d->points.ensure(d->max_points);
     d->stage_cap = (unsigned int)((double)g.npix * d->points_per_pixel) + 1024u;
     bad |= d->stage_rec.ensure((size_t)B * d->stage_cap);
@@ -379,25 +380,33 @@ static void launch_fit_class(asl_detector *d, const Geom &g, int cls, unsigned i
     switch (cls) {
     case 0:
         hipLaunchKernelGGL((k_fit_quads<64, true, CLASS0_CAP / 64>), dim3(qgrid), dim3(64), QUAD_LDS_BYTES(CLASS0_CAP), st, d->clusters.p, list, d->counters.p, 0,
-                           d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+                           d->max_clusters, CLASS0_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p, d->side_mom.p);
         break;
     case 1:  // two wavefronts per cluster: the 16 KB slab limits a CU to 7 workgroups, so wider workgroups keep more waves in flight
         hipLaunchKernelGGL((k_fit_quads<128, true, CLASS1_CAP / 128>), dim3(qgrid), dim3(128), QUAD_LDS_BYTES(CLASS1_CAP), st, d->clusters.p, list, d->counters.p, 1,
-                           d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+                           d->max_clusters, CLASS1_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p, d->side_mom.p);
         break;
     case 2:
         hipLaunchKernelGGL((k_fit_quads<256, true, CLASS2_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS2_CAP), st, d->clusters.p, list, d->counters.p, 2,
-                           d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+                           d->max_clusters, CLASS2_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p, d->side_mom.p);
         break;
     case 3:
         hipLaunchKernelGGL((k_fit_quads<256, true, CLASS3_CAP / 256>), dim3(q2grid), dim3(256), QUAD_LDS_BYTES(CLASS3_CAP), st, d->clusters.p, list, d->counters.p, 3,
-                           d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+                           d->max_clusters, CLASS3_CAP, d->points.p, d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p, d->side_mom.p);
         break;
     default:
         hipLaunchKernelGGL((k_fit_quads<256, false, 0>), dim3(q2grid), dim3(256), 0, st, d->clusters.p, list, d->counters.p, 4, d->max_clusters, 0, d->points.p,
-                           d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p);
+                           d->dgray.p, g, tag_width, want_rev, want_norm, d->scratch.p, d->quads.p, d->wtab.p, d->side_mom.p);
         break;
     }
+}
+
+static void launch_quad_finish(asl_detector *d, const Geom &g, hipStream_t st)
+{
+    int tag_width = d->fam.width_at_border / g.f;
+    if (tag_width < 3) tag_width = 3;
+    hipLaunchKernelGGL(k_quad_finish, dim3(std::min<unsigned int>((d->max_clusters + 63) / 64, 4096u)), dim3(256), 0, st, d->quads.p, d->side_mom.p, d->counters.p,
+                       d->max_clusters, tag_width);
 }
 
 static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
@@ -475,6 +484,8 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
         launch_fit_class(d, g, cls, B, st);
     }
 
+    STAGE("k_quad_finish");
+    launch_quad_finish(d, g, st);
     range_pop();
     range_push("S6-S7 edge refinement, homography, decode");
     STAGE("k_quad_compact");
@@ -1025,6 +1036,7 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
         for (int k = 0; k < 2 + NCLASSES; k++) o[k] = 0;
         for (size_t r = 0; r < reps; r++) {
             for (int cls = 0; cls < NCLASSES; cls++) launch_fit_class(d, g, cls, (unsigned int)g.nframes, nullptr);
+            launch_quad_finish(d, g, nullptr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpy((r ? cur : ref).data(), d->quads.p, ncl * sizeof(QuadRec), hipMemcpyDeviceToHost));
             if (!r) continue;
