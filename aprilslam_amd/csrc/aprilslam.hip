@@ -494,10 +494,10 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     unsigned int dgrid = std::min<unsigned int>(d->max_clusters, std::max<unsigned int>(8192u, 64u * B));
     STAGE("k_refine");
     hipLaunchKernelGGL((g.channels == 1 ? k_refine<1> : k_refine<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->counters.p, d->max_clusters, d_frames, g,
-                       d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p, d->quad_list.p);
+                       d->fam.reversed_border ? 1 : 0, d->refine, d->quadH.p, d->quad_list.p, d->side_mom.p);
     STAGE("k_homography");
     hipLaunchKernelGGL(k_homography, dim3(std::min<unsigned int>((d->max_clusters + 31) / 32, 2048u)), dim3(256), 0, st, d->quadH.p, d->counters.p, d->max_clusters,
-                       d->quad_list.p);
+                       d->quad_list.p, d->side_mom.p);
     STAGE("k_decode");
     hipLaunchKernelGGL((g.channels == 1 ? k_decode<1> : k_decode<3>), dim3(dgrid), dim3(64), 0, st, d->quads.p, d->quadH.p, d->counters.p, d->max_clusters, d_frames, g, d->fam,
                        d->maxhamming, d->dets.p, d->max_dets, d->counters.p, d->quad_list.p);
