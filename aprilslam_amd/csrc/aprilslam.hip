@@ -80,6 +80,8 @@ struct asl_detector {
     int pnp_both_minima = 0;
     FamilyDev fam;
     unsigned long long *d_codes = nullptr;
+    DevBuf<unsigned short> idx_start;        // code-book index of the family (FamilyDev), rebuilt when the id limit changes
+    DevBuf<unsigned long long> idx_entries;
 
     // capacities (grow on overflow)
     unsigned int hash_slots_per_frame = 1024;
@@ -150,6 +152,41 @@ static const char *kVersion = "aprilslam 0.1 gfx950 (HIP, tagStandard41h12)";
 extern "C" const char *asl_last_error(void) { return g_err.c_str(); }
 extern "C" const char *asl_version(void) { return kVersion; }
 
+// Code-book index for k_decode (asl_common.h: FamilyDev): maxhamming + 1 chunks of the code bits; a family wider than 48 bits
+// or with more than 65535 ids keeps idx_nch = 0 and is searched as a whole.
+static int build_code_index(asl_detector *d)
+{
+    FamilyDev &f = d->fam;
+    f.idx_nch = 0; f.idx_start = nullptr; f.idx_entries = nullptr;
+    const int nch = d->maxhamming + 1;
+    if (f.nbits > 48 || f.ncodes > 65535 || nch > IDX_MAX_CHUNKS) return 0;
+    if (getenv("ASL_NO_CODE_INDEX")) return 0;  // tests: the search of the whole book must agree with the index
+    std::vector<unsigned short> start((size_t)nch * (IDX_BUCKETS + 1), 0);
+    std::vector<unsigned long long> entries((size_t)nch * f.ncodes);
+    int lo = 0;
+    for (int c = 0; c < nch; c++) {
+        const int w = f.nbits / nch + (c < f.nbits % nch ? 1 : 0);
+        f.idx_lo[c] = lo; f.idx_w[c] = w;
+        std::vector<unsigned int> bucket(f.ncodes);
+        unsigned short *st = start.data() + (size_t)c * (IDX_BUCKETS + 1);
+        for (int i = 0; i < f.ncodes; i++) {
+            bucket[i] = idx_bucket((kTag41h12Codes[i] >> lo) & ((1ull << w) - 1ull), w);
+            st[bucket[i] + 1]++;
+        }
+        for (int b = 0; b < IDX_BUCKETS; b++) st[b + 1] = (unsigned short)(st[b + 1] + st[b]);
+        std::vector<unsigned short> fill(st, st + IDX_BUCKETS);
+        for (int i = 0; i < f.ncodes; i++)  // ids ascending inside a bucket
+            entries[(size_t)c * f.ncodes + fill[bucket[i]]++] = ((unsigned long long)i << 48) | kTag41h12Codes[i];
+        lo += w;
+    }
+    for (int c = nch; c < IDX_MAX_CHUNKS; c++) { f.idx_lo[c] = 0; f.idx_w[c] = 1; }
+    if (d->idx_start.ensure(start.size()) || d->idx_entries.ensure((size_t)IDX_MAX_CHUNKS * kTag41h12NCodes)) return -1;
+    if (hipMemcpy(d->idx_start.p, start.data(), start.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(d->idx_entries.p, entries.data(), entries.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    f.idx_start = d->idx_start.p; f.idx_entries = d->idx_entries.p; f.idx_nch = nch;
+    return 0;
+}
+
 extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamming, float decimate, float blur,
                                    int refine_edges, int device, asl_detector **out)
 {
@@ -189,6 +226,12 @@ extern "C" int asl_detector_create(const char *family, int nthreads, int maxhamm
         return fail(ASL_EDEVICE, "hipMemcpy(code book) failed");
     }
     d->fam.codes = d->d_codes;
+    if (build_code_index(d)) {
+        d->idx_start.release(); d->idx_entries.release();
+        (void)hipFree(d->d_codes);
+        delete d;
+        return fail(ASL_ENOMEM, "code-book index allocation failed");
+    }
     if (d->wtab.ensure(WEIGHT_TABLE_N)) {
         (void)hipFree(d->d_codes);
         delete d;
@@ -227,6 +270,7 @@ extern "C" void asl_detector_destroy(asl_detector *d)
     if (d->host_stream) (void)hipStreamDestroy(d->host_stream);
     for (hipEvent_t e : d->copy_done) (void)hipEventDestroy(e);
     if (d->d_codes) (void)hipFree(d->d_codes);
+    d->idx_start.release(); d->idx_entries.release();
     if (d->host_det) (void)hipHostFree(d->host_det);
     if (d->pinned_counters) (void)hipHostFree(d->pinned_counters);
     for (int i = 0; i <= MAX_STAGES; i++) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
@@ -239,6 +283,8 @@ extern "C" int asl_detector_set_id_limit(asl_detector *d, int n_ids)
     if (n_ids > kTag41h12NCodes) return fail(ASL_EINVAL, "the code table holds %d ids (asked for %d)", kTag41h12NCodes, n_ids);
     if (d->pending) return fail(ASL_EINVAL, "a batch is in flight on this detector");
     d->fam.ncodes = n_ids <= 0 ? kTag41h12NCodes : n_ids;
+    HIPCHK(hipSetDevice(d->device));
+    if (build_code_index(d)) return fail(ASL_ENOMEM, "code-book index allocation failed");
     return ASL_OK;
 }
 

@@ -77,11 +77,25 @@ struct DetRec {
     int32_t pose_ok, pad;
 };
 
+// Code-book index (k_decode): a word within maxhamming of a code agrees with it on at least one of maxhamming + 1 chunks
+// of the bits, so the codes are filed per chunk under the chunk's value (hashed to IDX_BUCKETS when the chunk is wider than
+// 12 bits) and a lookup compares the word with the handful of codes in its buckets instead of the whole book.
+#define IDX_BUCKET_BITS 12
+#define IDX_BUCKETS (1 << IDX_BUCKET_BITS)
+#define IDX_MAX_CHUNKS 4
 struct FamilyDev {
     int nbits, width_at_border, total_width, reversed_border, ncodes;
     int bit_x[64], bit_y[64];
     const unsigned long long *codes;  // device pointer
+    int idx_nch;                                  // chunks (0: no index, the book is searched as a whole)
+    int idx_lo[IDX_MAX_CHUNKS], idx_w[IDX_MAX_CHUNKS];  // first bit and width of every chunk
+    const unsigned short *idx_start;              // [chunk][IDX_BUCKETS + 1]: first entry of every bucket
+    const unsigned long long *idx_entries;        // [chunk][ncodes]: id << 48 | code, by bucket, ids ascending
 };
+__host__ __device__ __forceinline__ unsigned int idx_bucket(unsigned long long chunk_value, int width)
+{
+    return width <= IDX_BUCKET_BITS ? (unsigned int)chunk_value : (unsigned int)((chunk_value * 0x9E3779B97F4A7C15ull) >> (64 - IDX_BUCKET_BITS));
+}
 
 struct CamDev {
     double fx, fy, cx, cy, k1, k2, p1, p2, k3;

@@ -373,3 +373,44 @@ def test_reference_trajectory_on_gpu(gpu_detector, family):
         nodes.append(len(slam.graph.get_nodes()))
     d_ref, d_rpy = G.check_trajectory(poses, ids, nodes)
     assert d_ref[0] < 0.02
+
+
+@pytest.mark.parametrize("maxhamming", [0, 1, 2, 3])
+def test_code_book_index_with_damaged_payloads(family, maxhamming, monkeypatch):
+    """Tags whose payload has 0..4 flipped cells, decoded with every maxhamming: the code-book index of k_decode (a word
+    within maxhamming of a code shares one of maxhamming + 1 bit chunks with it) against the oracle's search of the whole
+    book, and against the device's own whole-book search (ASL_NO_CODE_INDEX)."""
+    from aprilslam_amd import _lib
+    from aprilslam_amd.families import get_family
+    fam = get_family("tagStandard41h12")
+    rng = np.random.default_rng(77 + maxhamming)
+    w, h = 1280, 720
+    tags = synth.random_scene(w, h, 12, np.random.default_rng(5))
+    textures = {}
+    flips = {}
+    off = (fam.total_width - fam.width_at_border) // 2
+    for k, t in enumerate(tags):
+        g = fam.grid(t["id"]).copy()
+        nflip = k % 5
+        for i in rng.choice(fam.nbits, size=nflip, replace=False):
+            g[fam.bit_y[i] + off, fam.bit_x[i] + off] ^= 1
+        flips[t["id"]] = nflip
+        textures[t["id"]] = np.repeat((np.kron(g, np.ones((40, 40), dtype=np.uint8)) * 255)[:, :, None], 3, axis=2)
+    frame, _ = synth.render_frame(w, h, tags, 18.0, textures=textures)
+    ref = O.detect_gray(O.bgr2gray(frame), family, 2, maxhamming=maxhamming)
+    results = []
+    for no_index in (False, True):
+        if no_index:
+            monkeypatch.setenv("ASL_NO_CODE_INDEX", "1")
+        det = _lib.Detector("tagStandard41h12", decimate=2.0, id_limit=0, maxhamming=maxhamming)
+        try:
+            dets, _, npf = det.detect_host(frame[None], K=synth.camera_matrix(w, h), dist=np.zeros(4), tag_size=10.0)
+            results.append([(int(d["id"]), int(d["hamming"])) for d in dets])
+        finally:
+            det.close()
+    assert results[0] == results[1] == [(r["id"], r["hamming"]) for r in ref]
+    seen = dict(results[0])
+    for tid, nflip in flips.items():
+        if nflip <= maxhamming:
+            assert seen.get(tid) == nflip, (tid, nflip, seen.get(tid))
+    assert max(hm for _, hm in results[0]) == min(maxhamming, 4)
