@@ -422,7 +422,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1", help="BASELINE.json config to run (default: the one the metric is quoted on)")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (tiled to --batch); 0 = every frame of the batch is distinct")
-    ap.add_argument("--pipeline", type=int, default=2, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
+    ap.add_argument("--pipeline", type=int, default=3, help="detector workspaces/streams per GPU; the batch is split among them so one part's host post-processing and latency-bound tail kernels overlap the other part's bulk kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="only the warm-up, the timed steps and the one isolated batch: no h2d / render / both-minima / projection / CPU legs (for rocprofv3 passes: every detector launch then has the full batch size)")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank rehearsal on a one-GPU box: gloo backend, every rank on cuda:0")
