@@ -135,4 +135,8 @@ for src, dst_name in ((tag + "_config3.json", tag + "_config3_detect_pnp_gn.json
                       (tag + "_bench_configs4_rehearse_gpus2.json", tag + "_bench_configs4_rehearse_gpus2_gloo.json"),
                       (tag + "_marker_trace.csv", tag + "_marker_trace.csv")):
     if os.path.exists(os.path.join(G, src)):
-        shutil.copy(os.path.join(G, src), os.path.join(P, dst_name))
+        if src.endswith(".json"):  # a library may have written to stdout before the line (gloo's connection notice)
+            lines = [ln for ln in open(os.path.join(G, src)) if ln.startswith("{")]
+            open(os.path.join(P, dst_name), "w").write(lines[-1] if lines else open(os.path.join(G, src)).read())
+        else:
+            shutil.copy(os.path.join(G, src), os.path.join(P, dst_name))
