@@ -412,7 +412,6 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
         }                                                                  \
     } while (0)
 
-// enqueue the whole detector for frames resident at d_frames; no host sync
 // Quad fit of one size class (k_quad.inc): grid-stride kernels over the class's device-side cluster list -- many more
 // workgroups than fit on the chip, so the heavy-tailed per-cluster costs balance out (workgroups without work leave at once).
 static void launch_fit_class(asl_detector *d, const Geom &g, int cls, unsigned int B, hipStream_t st)
@@ -455,6 +454,7 @@ static void launch_quad_finish(asl_detector *d, const Geom &g, hipStream_t st)
                        d->max_clusters, tag_width);
 }
 
+// enqueue the whole detector for frames resident at d_frames; no host sync
 static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &g, hipStream_t st, const CamDev *cam)
 {
     dim3 blk(64, 4, 1);
