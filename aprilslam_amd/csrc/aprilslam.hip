@@ -365,8 +365,8 @@ static int ensure_workspace(asl_detector *d, const Geom &g)
     d->max_dets = (unsigned int)std::min<unsigned long long>((unsigned long long)B * d->dets_per_frame, 0x7FFFFFFFull);
     int bad = 0;
     bad |= d->dgray.ensure(total);
-    bad |= d->tmin.ensure(B * (size_t)std::max(1, g.tw * g.th));
-    bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th));
+    bad |= d->tmin.ensure(B * (size_t)std::max(1, g.tw * g.th) + 8);  // + 8: k_tile_cut's last 8-byte load
+    bad |= d->tmax.ensure(B * (size_t)std::max(1, g.tw * g.th) + 8);
     bad |= d->tcut.ensure(B * (size_t)std::max(1, g.tw * g.th));
     bad |= d->parent.ensure(total);
     bad |= d->sizes.ensure(total);
@@ -483,7 +483,7 @@ static int enqueue_detect(asl_detector *d, const uint8_t *d_frames, const Geom &
     const size_t nwords = (size_t)B * g.sh * nwx;
     STAGE("k_tile_cut");
     if (g.tw > 0 && g.th > 0)
-        hipLaunchKernelGGL(k_tile_cut, dim3((((g.tw + 3) / 4) * g.th + 255) / 256, B), dim3(256), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
+        hipLaunchKernelGGL(k_tile_cut, dim3((((g.tw + 3) / 4) * ((g.th + 3) / 4) + 255) / 256, B), dim3(256), 0, st, d->tmin.p, d->tmax.p, g, d->tcut.p);
     STAGE("k_seg_tile");
     {
         const int ntiles = nwx * ((g.sh + SEG_TH - 1) / SEG_TH);

@@ -25,9 +25,9 @@ cyc = det.phase_cycles()
 names = {0: "fit: bbox/polarity", 1: "fit: keys+sort", 2: "fit: dedup compact", 3: "fit: weights", 4: "fit: moment scan",
          5: "fit: errs+smooth", 6: "fit: maxima select", 7: "fit: combos", 8: "fit: final",
          16: "ref: load", 17: "ref: edges", 18: "dec: load H", 19: "dec: border+graymodel", 20: "dec: bits+sharpen",
-         21: "dec: code book", 22: "ref: homography", 23: "dec: emit", 24: "ref: normals", 25: "ref: probes fetch+park", 26: "ref: steps+centroid", 27: "ref: ordered line fit", 32: "pts: masks+run list", 33: "pts: run labels", 34: "pts: sites+tile table", 35: "pts: global table",
+         21: "dec: code book", 22: "ref: homography", 23: "dec: emit", 24: "ref: normals", 25: "ref: probes fetch+park", 26: "ref: steps+centroid", 27: "ref: ordered line fit", 32: "pts: masks+run list", 33: "pts: run labels", 34: "pts: items -> tile table", 37: "pts: site masks + item list", 35: "pts: global table",
          36: "pts: write out", 40: "tile: threshold+masks", 41: "tile: unions", 42: "tile: run roots+sizes", 43: "tile: roots out"}
-for grp in ((0, 9), (16, 18), (24, 28), (22, 23), (18, 22), (23, 24), (32, 37), (40, 45)):
+for grp in ((0, 9), (16, 18), (24, 28), (22, 23), (18, 22), (23, 24), (32, 38), (40, 45)):
     tot = float(cyc[grp[0]:grp[1]].sum()) or 1.0
     for k in range(*grp):
         print("%-24s %14d cycles  %5.1f%%" % (names.get(k, str(k)), int(cyc[k]), 100.0 * float(cyc[k]) / tot))
