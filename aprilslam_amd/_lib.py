@@ -375,6 +375,13 @@ class Detector:
         check(self._L.asl_debug_fetch(self._h, 7, buf.ctypes.data, int(reps), C.byref(n)))
         return buf
 
+    def debug_division_check(self, exponent_limit=100):
+        """(pairs, mismatches) of div_by(a, recip_of(d)) against a / d on the device, exponents within +-exponent_limit."""
+        buf = np.zeros(2, dtype=np.int64)
+        n = C.c_size_t()
+        check(self._L.asl_debug_fetch(self._h, 8, buf.ctypes.data, int(exponent_limit), C.byref(n)))
+        return int(buf[0]), int(buf[1])
+
     def phase_cycles(self, reset=True):
         buf = (C.c_uint64 * 64)()
         check(self._L.asl_debug_phase_cycles(self._h, buf, 1 if reset else 0))

@@ -966,6 +966,28 @@ extern "C" int asl_solve_pnp_batch(asl_detector *d, const float *corners, const 
     return ASL_OK;
 }
 
+// asl_debug_fetch item 8: div_by(a, recip_of(d)) (asl_common.h) against a / d, as compiled into this library: log-uniform
+// magnitudes with exponents within +-lim, both signs, a = 0 now and then
+__global__ void __launch_bounds__(256) k_div_check(unsigned long long seed, int per_thread, int lim, unsigned long long *bad)
+{
+    unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1);
+    auto rng = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (int i = 0; i < 8; i++) rng();
+    unsigned long long nbad = 0;
+    for (int i = 0; i < per_thread; i++) {
+        const unsigned long long u = rng(), v = rng(), w = rng();
+        const int ea = (int)(u % (unsigned)(2 * lim + 1)) - lim, ed = (int)((u >> 20) % (unsigned)(2 * lim + 1)) - lim;
+        double a = ldexp(1.0 + (double)(v & 0xFFFFFFFFFFFFFull) * 0x1p-52, ea);
+        double dd = ldexp(1.0 + (double)(w & 0xFFFFFFFFFFFFFull) * 0x1p-52, ed);
+        if (u & (1ull << 60)) a = -a;
+        if (u & (1ull << 61)) dd = -dd;
+        if ((u >> 40) % 257 == 0) a = 0.0;
+        const double want = a / dd, got = div_by(a, recip_of(dd));
+        if (__double_as_longlong(want) != __double_as_longlong(got)) nbad++;
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t bytes, size_t *n_items)
 {
     if (!d || !dst || !n_items) return fail(ASL_EINVAL, "NULL argument");
@@ -1096,6 +1118,20 @@ extern "C" int asl_debug_fetch(asl_detector *d, int what, void *dst, size_t byte
         }
         o[0] = (long long)reps;
         *n_items = 2 + NCLASSES;
+        return ASL_OK;
+    }
+    case 8: {  // the shared-reciprocal division of the line fits against the compiler's division: dst int64[2] = pairs, mismatches
+        unsigned long long *d_bad = nullptr, h_bad = 0;
+        const int lim = bytes > 0 && bytes <= 900 ? (int)bytes : 100, blocks = 2048, per = 1024;
+        HIPCHK(hipMalloc((void **)&d_bad, sizeof h_bad));
+        HIPCHK(hipMemset(d_bad, 0, sizeof h_bad));
+        hipLaunchKernelGGL(k_div_check, dim3(blocks), dim3(256), 0, nullptr, 20260301ull, per, lim, d_bad);
+        hipError_t e8 = hipMemcpy(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost);
+        (void)hipFree(d_bad);
+        if (e8 != hipSuccess) return fail(ASL_EDEVICE, "division check failed: %s", hipGetErrorString(e8));
+        ((long long *)dst)[0] = (long long)blocks * 256 * per;
+        ((long long *)dst)[1] = (long long)h_bad;
+        *n_items = 2;
         return ASL_OK;
     }
     default:

@@ -265,3 +265,16 @@ def test_quad_fit_gives_the_same_quads_every_time():
         assert int(r[0]) == 3000 and int(r[1]) == 0, r.tolist()
     finally:
         det.close()
+
+
+def test_shared_reciprocal_division_is_the_ieee_quotient():
+    """asl_common.h's div_by(a, recip_of(d)) -- the five quotients of a line fit over one denominator -- against the
+    compiler's a / d, as compiled into the shipped library: bit for bit on 2^29 random pairs, exponents within +-100 and
+    +-400 (the quad path's operands are within 2^+-80)."""
+    det = _lib.Detector("tagStandard41h12")
+    try:
+        for lim in (100, 400):
+            pairs, bad = det.debug_division_check(lim)
+            assert pairs == 2048 * 256 * 1024 and bad == 0, (lim, pairs, bad)
+    finally:
+        det.close()
