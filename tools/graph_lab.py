@@ -41,3 +41,39 @@ for world in (1, 2, 4, 8):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print("world %d: %d frames, graph_frames_device %.3f ms (min of 5 after warm-up), steady frames %d" % (world, world * B, min(ts[1:]), int((status == 0).sum())))
+
+# the read-back of a world = 8 step, piece by piece (wall clock around a synchronize each)
+import time  # noqa: E402
+
+world = 8
+block = obs[None].repeat(world, 1, 1, 1).contiguous()
+pose = torch.zeros((world * B, 16), dtype=torch.float64, device=dev)
+status = torch.zeros(world * B, dtype=torch.uint8, device=dev)
+last = torch.zeros(adist.MAX_IDS, dtype=torch.int32, device=dev)
+picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+h_pose, h_status = torch.zeros((world * B, 16), dtype=torch.float64).pin_memory(), torch.zeros(world * B, dtype=torch.uint8).pin_memory()
+h_last = torch.zeros(adist.MAX_IDS, dtype=torch.int32).pin_memory()
+h_picks = torch.zeros((2 * adist.MAX_IDS, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+h_tail = torch.zeros((world, MT, adist.OBS_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+print("bytes: pose %d status %d last %d picks %d tail %d" % (h_pose.numel() * 8, h_status.numel(), h_last.numel() * 4, h_picks.numel(), h_tail.numel()))
+
+
+def timed(name, fn, reps=5):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    print("  %-28s %.3f ms" % (name, min(ts)))
+
+
+timed("last.zero_", lambda: last.zero_())
+timed("graph_frames_device", lambda: det.graph_frames_device(block.data_ptr(), world, B, MT, 0, pose.data_ptr(), status.data_ptr(), last.data_ptr(), adist.MAX_IDS,
+                                                             picks_ptr=picks.data_ptr(), stream=st))
+timed("pose -> host", lambda: h_pose.copy_(pose, non_blocking=True))
+timed("status -> host", lambda: h_status.copy_(status, non_blocking=True))
+timed("last -> host", lambda: h_last.copy_(last, non_blocking=True))
+timed("picks -> host", lambda: h_picks.copy_(picks, non_blocking=True))
+timed("tail -> host", lambda: h_tail.copy_(block[:, B - 1], non_blocking=True))
