@@ -278,3 +278,31 @@ def test_shared_reciprocal_division_is_the_ieee_quotient():
             assert pairs == 2048 * 256 * 1024 and bad == 0, (lim, pairs, bad)
     finally:
         det.close()
+
+
+def test_a_batch_gives_the_same_bytes_every_time():
+    """400 runs of one 256-frame batch through one detector: detections, poses and per-frame counts byte for byte the same
+    (atomics decide where things are stored, never what).  The race test_quad_fit_gives_the_same_quads_every_time is about
+    changed one run in ~170 at four times this batch size; tools/race_hunt.py reports such a difference stage by stage."""
+    import torch
+
+    import bench
+    det = _lib.Detector("tagStandard41h12", decimate=2.0, id_limit=0)
+    try:
+        dev = torch.device("cuda", 0)
+        B = 256
+        d_frames, _, _ = bench.render_stream_device(det, B, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        K = synth.camera_matrix(bench.W, bench.H)
+        first = None
+        for it in range(400):
+            det.submit_device(d_frames.data_ptr(), B, 3, bench.W, bench.H, stream=st, K=K, dist=np.zeros(4), tag_size=bench.TAG_INNER)
+            dets, poses, npf = det.collect(max_per_frame=bench.MAXDET)
+            cur = (dets.tobytes(), poses.tobytes(), npf.tobytes())
+            if first is None:
+                first = cur
+                assert len(dets) == 20 * B
+            else:
+                assert cur == first, "repetition %d differs from the first" % it
+    finally:
+        det.close()
