@@ -211,7 +211,8 @@ int asl_render_frames_device(asl_detector *det, void *d_frames, int n_frames, in
          4 = candidate quads (asl_debug_quad, count via *n_items)
          5 = stage counters (int64[18]: frames, sw, sh, clusters, points, quads, detections, ..., tiles of the two dense launches)
          7 = diagnostic: re-run the quad fit of the last batch `bytes` times on the device buffers it left behind; dst receives
-             int64[7]: repetitions, quads that differ from the first repetition, and those by size class (any is a race)
+             int64[7]: repetitions, quads that differ from the first repetition, and those by size class (any is a race); clusters of
+             more than 1024 points are left out: their fit sorts in place, a second run would not see the same input
          8 = diagnostic: the shared-reciprocal division of the line fits (asl_common.h) against the compiler's on 2^29 random
              operand pairs with exponents within +-`bytes` (default 100); dst receives int64[2]: pairs, mismatches
          6 = clusters handed to the quad fit (uint64[3] each: key, points, hash of the sorted point records), ordered by key

@@ -12,6 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench  # noqa: E402
 from aprilslam_amd import _lib, synth  # noqa: E402
 
@@ -20,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--clutter", type=int, default=0, help="instead of the bench scene: a batch of this many cluttered 720p frames (tools/fuzz_clutter.py: noise, stripes, "
+                    "checkerboards over tag scenes -- the dense launches, the large size classes, buffers that grow)")
     ap.add_argument("--refit", type=int, default=0, help="after one batch, re-run only the quad fit this many times (asl_debug_fetch item 7)")
     ap.add_argument("--quads", action="store_true", help="compare the quads of every repetition; on a difference also the clusters")
     ap.add_argument("--deep", action="store_true", help="also compare labels, sizes, clusters (sorted points) and quads of every repetition")
@@ -27,7 +30,18 @@ def main():
     dev = torch.device("cuda", 0)
     B = args.batch
     det = _lib.Detector(id_limit=0, decimate=2.0)
-    d_frames, _, _ = bench.render_stream_device(det, B, dev)
+    if args.clutter:
+        import fuzz_clutter
+        rng = np.random.default_rng(4711)
+        B = args.clutter
+        frames = []
+        for _ in range(B):
+            tags = synth.random_scene(bench.W, bench.H, int(rng.integers(1, 6)), rng)
+            f, _ = synth.render_frame(bench.W, bench.H, tags, 18.0, cam_position=tuple(rng.uniform(-2, 2, 3)), cam_rotation_deg=tuple(rng.uniform(-3, 3, 3)))
+            frames.append(fuzz_clutter.clutter(f, rng))
+        d_frames = torch.from_numpy(np.stack(frames)).to(dev)
+    else:
+        d_frames, _, _ = bench.render_stream_device(det, B, dev)
     K = synth.camera_matrix(bench.W, bench.H)
     st = torch.cuda.current_stream(dev).cuda_stream
     if args.refit:
@@ -40,7 +54,7 @@ def main():
     nbad = 0
     for it in range(args.reps):
         det.submit_device(d_frames.data_ptr(), B, 3, bench.W, bench.H, stream=st, K=K, dist=np.zeros(4), tag_size=bench.TAG_INNER)
-        dets, poses, npf = det.collect(max_per_frame=bench.MAXDET)
+        dets, poses, npf = det.collect(max_per_frame=max(bench.MAXDET, 256))
         cur = (np.array(dets, copy=True), np.array(poses, copy=True), np.array(npf, copy=True), det.debug_counters().tolist())
         if args.quads:
             q = det.debug_quads(cap=1 << 20).copy()
